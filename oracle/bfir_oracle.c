@@ -1,0 +1,281 @@
+/*
+ * bfir_oracle.c -- CPU oracle for the partitioned-FIR hot path (plain C).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see bfir_oracle.h.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off, no dependencies)
+ */
+#define _USE_MATH_DEFINES
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bfir_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define REAL float
+#define SUF(x) x##_f
+#include "bfir_oracle_impl.inc"
+#undef REAL
+#undef SUF
+
+#define REAL double
+#define SUF(x) x##_d
+#include "bfir_oracle_impl.inc"
+#undef REAL
+#undef SUF
+
+#define ORC_MAXCH 8 /* BF_MAXCHANNELS, brutefir/global.h:21 */
+
+/* State of one brutefir instance (brutefir/brutefir.hpp:96-127), kept as
+ * untyped byte buffers whose element type follows realsize. */
+struct orc_engine {
+    int L, N, B, s, C;
+    int in_bytes, out_bytes;         /* raw sample widths                    */
+    double in_scale, out_scale;      /* sample_format_t.scale                */
+    int curbuf;
+    unsigned int blockcounter;
+    int procblocks[ORC_MAXCH];
+    int coeff_blocks[ORC_MAXCH];     /* bfcoeff_t.n_blocks                   */
+    uint8_t *coeff[ORC_MAXCH];       /* [coeff_blocks][N] reals, or NULL     */
+    uint8_t *fdl[ORC_MAXCH];         /* cbuf[n][B]: delay line of spectra    */
+    uint8_t *ocbuf[ORC_MAXCH];
+    uint8_t *timebuf[ORC_MAXCH][2];  /* input_timecbuf                       */
+    uint8_t *ifreq, *ofreq, *tout;
+    orc_overflow_t overflow[ORC_MAXCH];
+    int initialized;
+};
+
+static int fmt_bytes(int fmt)
+{
+    /* brutefir/brutefir.cpp:512-538: the two formats on the measured path */
+    if (fmt == ORC_FMT_FLOAT_LE) return 4;
+    if (fmt == ORC_FMT_FLOAT64_LE) return 8;
+    return 0;
+}
+
+orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
+                              int in_format, int out_format)
+{
+    orc_engine *e;
+    int n, lg = 0;
+    size_t cb;
+    if (realsize != 4 && realsize != 8) return NULL;            /* fftw_convolver.cpp:64 */
+    while ((1 << lg) < filter_length) lg++;
+    if (filter_length < 4 || (1 << lg) != filter_length) return NULL; /* :70 */
+    if (channels < 1 || channels > ORC_MAXCH) return NULL;      /* brutefir.cpp:652 */
+    if (filter_blocks < 1) return NULL;
+    if (!fmt_bytes(in_format) || !fmt_bytes(out_format)) return NULL;
+    e = (orc_engine *)calloc(1, sizeof(*e));
+    e->L = filter_length; e->N = 2 * filter_length; e->B = filter_blocks;
+    e->s = realsize; e->C = channels;
+    e->in_bytes = fmt_bytes(in_format); e->out_bytes = fmt_bytes(out_format);
+    e->in_scale = 1.0; e->out_scale = 1.0;                      /* float formats: scale 1 */
+    cb = (size_t)e->N * (size_t)e->s;                           /* convolver_cbufsize */
+    for (n = 0; n < e->C; n++) {
+        /* brutefir.cpp:758-807: zero-initialised work buffers; with one
+         * partition the delay line and ocbuf are the same buffer. */
+        e->fdl[n] = (uint8_t *)calloc((size_t)e->B, cb);
+        e->ocbuf[n] = (e->B > 1) ? (uint8_t *)calloc(1, cb) : e->fdl[n];
+        e->timebuf[n][0] = (uint8_t *)calloc(1, cb);
+        e->timebuf[n][1] = (uint8_t *)calloc(1, cb);
+        e->overflow[n].max = 1.0;                               /* brutefir.cpp:674-678 */
+    }
+    e->ifreq = (uint8_t *)calloc(1, cb);
+    e->ofreq = (uint8_t *)calloc(1, cb);
+    e->tout = (uint8_t *)calloc(1, cb);
+    orc_engine_reset(e);
+    return e;
+}
+
+static void free_coeff(orc_engine *e)
+{
+    int n;
+    for (n = 0; n < ORC_MAXCH; n++) { free(e->coeff[n]); e->coeff[n] = NULL; }
+    e->initialized = 0;
+}
+
+void orc_engine_destroy(orc_engine *e)
+{
+    int n;
+    if (!e) return;
+    free_coeff(e);
+    for (n = 0; n < e->C; n++) {
+        if (e->B > 1) free(e->ocbuf[n]);
+        free(e->fdl[n]); free(e->timebuf[n][0]); free(e->timebuf[n][1]);
+    }
+    free(e->ifreq); free(e->ofreq); free(e->tout);
+    free(e);
+}
+
+/* coeff::preprocess_coeff (brutefir/coeff.cpp:292-354) for one channel:
+ * block n takes taps [n*L, (n+1)*L) of the impulse; a short tail block is
+ * zero filled, blocks wholly past the end are all zero. */
+static int preprocess_coeff(orc_engine *e, const void *taps, int coeff_blocks, int coeff_length,
+                            double scale, uint8_t *dest)
+{
+    size_t cb = (size_t)e->N * (size_t)e->s;
+    int n, rc = 0;
+    for (n = 0; n < coeff_blocks; n++) {
+        long start = (long)n * e->L;
+        int count;
+        const uint8_t *src = (const uint8_t *)taps + (size_t)start * (size_t)e->s;
+        if (start > coeff_length) { count = 0; src = (const uint8_t *)taps; }
+        else if (start + e->L > coeff_length) count = coeff_length - (int)start;
+        else count = e->L;
+        if (e->s == 4) rc |= orc_coeffs2cbuf_f(e->L, (const float *)src, count, scale,
+                                               (float *)(dest + n * cb));
+        else rc |= orc_coeffs2cbuf_d(e->L, (const double *)src, count, scale,
+                                     (double *)(dest + n * cb));
+    }
+    return rc;
+}
+
+int orc_engine_set_coeff(orc_engine *e, const void *const *coeffs, int n_coeffs, int length,
+                         int coeff_blocks, double scale)
+{
+    size_t cb = (size_t)e->N * (size_t)e->s;
+    int n;
+    free_coeff(e);
+    if (n_coeffs > e->C) n_coeffs = e->C;                      /* brutefir.cpp:190-193 */
+    for (n = 0; n < n_coeffs; n++) {
+        e->coeff[n] = (uint8_t *)calloc((size_t)coeff_blocks, cb);
+        e->coeff_blocks[n] = coeff_blocks;
+        if (preprocess_coeff(e, coeffs[n], coeff_blocks, length, scale, e->coeff[n]) != 0) {
+            free_coeff(e);
+            return -2;                                         /* brutefir.cpp:217-222 */
+        }
+    }
+    /* The reference leaves channels beyond n_coeffs without spectra and would
+     * dereference NULL in run() (brutefir.cpp:288); here they get all-zero
+     * partitions (silence), which is what the HIP engine does too. */
+    for (; n < e->C; n++) {
+        e->coeff[n] = (uint8_t *)calloc((size_t)coeff_blocks, cb);
+        e->coeff_blocks[n] = coeff_blocks;
+    }
+    e->initialized = 1;
+    return 0;
+}
+
+void orc_engine_reset(orc_engine *e)
+{
+    int n;
+    for (n = 0; n < e->C; n++) {
+        e->overflow[n].n_overflows = 0;
+        e->overflow[n].largest = 0;
+        e->overflow[n].intlargest = 0;
+    }
+    memset(e->procblocks, 0, sizeof(e->procblocks));
+    e->curbuf = 0;
+    e->blockcounter = 0;
+}
+
+void orc_engine_get_overflow(const orc_engine *e, int channel, orc_overflow_t *of)
+{
+    *of = e->overflow[channel];
+}
+
+const void *orc_engine_coeff_block(const orc_engine *e, int ch, int block)
+{
+    if (!e->coeff[ch]) return NULL;
+    return e->coeff[ch] + (size_t)block * (size_t)e->N * (size_t)e->s;
+}
+
+/* brutefir::run (brutefir/brutefir.cpp:244-343). */
+int orc_engine_run(orc_engine *e, const void *inbuf, void *outbuf)
+{
+    size_t cb = (size_t)e->N * (size_t)e->s;
+    int n, i;
+    for (n = 0; n < e->C; n++) {
+        uint8_t *tcur = e->timebuf[n][e->curbuf], *tnext = e->timebuf[n][!e->curbuf];
+        int curblock, finite;
+        /* :255-263 staging in + forward transform */
+        if (e->s == 4) {
+            orc_raw2cbuf_f(e->L, inbuf, n * e->in_bytes, e->in_bytes, e->C,
+                           (float *)tcur, (float *)tnext);
+            orc_r2hc_f(e->N, (const float *)tcur, (float *)e->ifreq);
+        } else {
+            orc_raw2cbuf_d(e->L, inbuf, n * e->in_bytes, e->in_bytes, e->C,
+                           (double *)tcur, (double *)tnext);
+            orc_r2hc_d(e->N, (const double *)tcur, (double *)e->ifreq);
+        }
+        if (e->procblocks[n] < e->B) e->procblocks[n]++;       /* :265-268 */
+        curblock = (int)(e->blockcounter % (unsigned int)e->B); /* :270 */
+        /* :273-307 delay-line write, partition loop, output reorder */
+        if (e->s == 4) {
+            float *slot = (float *)(e->fdl[n] + curblock * cb);
+            orc_mixnscale_f(e->N, (const float *)e->ifreq, slot, e->in_scale, ORC_MIXMODE_INPUT);
+            if (e->B == 1) {
+                orc_convolve_inplace_f(e->N, (float *)e->fdl[n], (const float *)e->coeff[n]);
+            } else {
+                orc_convolve_f(e->N, slot, (const float *)e->coeff[n], (float *)e->ocbuf[n]);
+                for (i = 1; i < e->coeff_blocks[n] && i < e->procblocks[n]; i++) {
+                    int cv = (int)((e->blockcounter - (unsigned int)i) % (unsigned int)e->B);
+                    orc_convolve_add_f(e->N, (const float *)(e->fdl[n] + cv * cb),
+                                       (const float *)(e->coeff[n] + i * cb),
+                                       (float *)e->ocbuf[n]);
+                }
+            }
+            orc_mixnscale_f(e->N, (const float *)e->ocbuf[n], (float *)e->ofreq, e->out_scale,
+                            ORC_MIXMODE_OUTPUT);
+            orc_hc2r_f(e->N, (const float *)e->ofreq, (float *)e->tout);   /* :311 */
+            finite = isfinite((double)((float *)e->tout)[0]);              /* :316-321 */
+        } else {
+            double *slot = (double *)(e->fdl[n] + curblock * cb);
+            orc_mixnscale_d(e->N, (const double *)e->ifreq, slot, e->in_scale, ORC_MIXMODE_INPUT);
+            if (e->B == 1) {
+                orc_convolve_inplace_d(e->N, (double *)e->fdl[n], (const double *)e->coeff[n]);
+            } else {
+                orc_convolve_d(e->N, slot, (const double *)e->coeff[n], (double *)e->ocbuf[n]);
+                for (i = 1; i < e->coeff_blocks[n] && i < e->procblocks[n]; i++) {
+                    int cv = (int)((e->blockcounter - (unsigned int)i) % (unsigned int)e->B);
+                    orc_convolve_add_d(e->N, (const double *)(e->fdl[n] + cv * cb),
+                                       (const double *)(e->coeff[n] + i * cb),
+                                       (double *)e->ocbuf[n]);
+                }
+            }
+            orc_mixnscale_d(e->N, (const double *)e->ocbuf[n], (double *)e->ofreq, e->out_scale,
+                            ORC_MIXMODE_OUTPUT);
+            orc_hc2r_d(e->N, (const double *)e->ofreq, (double *)e->tout);
+            finite = isfinite(((double *)e->tout)[0]);
+        }
+        if (!finite) return -1;
+        /* :326-334 staging out: the first L samples are the valid half */
+        if (e->s == 4)
+            orc_real2raw_f((uint8_t *)outbuf + n * e->out_bytes, (const float *)e->tout,
+                           e->out_bytes, e->C, e->L, &e->overflow[n]);
+        else
+            orc_real2raw_d((uint8_t *)outbuf + n * e->out_bytes, (const double *)e->tout,
+                           e->out_bytes, e->C, e->L, &e->overflow[n]);
+    }
+    e->curbuf = !e->curbuf;                                    /* :337 */
+    e->blockcounter++;                                         /* :340 */
+    return 0;
+}
+
+int orc_engine_run_blocks(orc_engine *e, const void *inbuf, void *outbuf, int n_blocks)
+{
+    size_t istep = (size_t)e->L * (size_t)e->C * (size_t)e->in_bytes;
+    size_t ostep = (size_t)e->L * (size_t)e->C * (size_t)e->out_bytes;
+    int t, rc;
+    for (t = 0; t < n_blocks; t++) {
+        rc = orc_engine_run(e, (const uint8_t *)inbuf + t * istep, (uint8_t *)outbuf + t * ostep);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+/* Independent checker: direct-form convolution, long double accumulation. */
+void orc_direct_conv(const double *x, int n_x, const double *h, int n_h, double *y)
+{
+    int n, k;
+    for (n = 0; n < n_x; n++) {
+        long double acc = 0.0L;
+        int kmax = (n < n_h - 1) ? n : n_h - 1;
+        for (k = 0; k <= kmax; k++) acc += (long double)h[k] * (long double)x[n - k];
+        y[n] = (double)acc;
+    }
+}

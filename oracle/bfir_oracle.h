@@ -1,0 +1,131 @@
+/*
+ * bfir_oracle.h -- CPU oracle for the partitioned-FIR hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithm
+ * of the reference (vsu/foo-dsp-bfir, brutefir/) used as the *checker* for
+ * the HIP engine.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (libbfir_hip.so and the host
+ * layer above it) never links, loads or calls anything in oracle/.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or
+ * fixtures for this path, its own sources cannot be
+ * built in this image without stand-ins for MSVC/Win32 headers and for the
+ * FFTW 3.3-beta1 library (only Win32 DLLs are in the tree), so this oracle is
+ * not checked against outputs of the reference itself.  What pins it instead:
+ * an independent long-double direct-form convolution (orc_direct_conv) and
+ * scipy's pocketfft (tests/test_oracle.py).
+ *
+ * Third-party arithmetic restated: FFTW 3.3-beta1 r2r transforms FFTW_R2HC
+ * and FFTW_HC2R (call sites brutefir/fftw_convolver.cpp:204-209, 367-372,
+ * 500-517, 798-806).  Published definition (FFTW manual, "The Halfcomplex-
+ * format DFT"): unnormalised; R2HC output is r0, r1, ..., r_{n/2},
+ * i_{(n+1)/2-1}, ..., i_1 with X_k = sum_j x_j exp(-2 pi i j k / n);
+ * HC2R is its unnormalised inverse (HC2R(R2HC(x)) = n x).
+ */
+#ifndef BFIR_ORACLE_H
+#define BFIR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sample format codes: brutefir/global.h:24-34 */
+#define ORC_FMT_FLOAT_LE   8
+#define ORC_FMT_FLOAT64_LE 10
+
+/* brutefir/fftw_convolver.hpp:14-16 */
+#define ORC_MIXMODE_INPUT  1
+#define ORC_MIXMODE_OUTPUT 3
+
+/* brutefir/global.h:96-102 */
+typedef struct {
+    unsigned int n_overflows;
+    int32_t intlargest;
+    double largest;
+    double max;
+} orc_overflow_t;
+
+/* ---- stage level: one function per reference loop (realsize 4 / 8) ---- */
+
+/* FFTW_R2HC / FFTW_HC2R of length n (power of two >= 4), out of place or in place. */
+void orc_r2hc_f(int n, const float *in, float *out);
+void orc_hc2r_f(int n, const float *in, float *out);
+void orc_r2hc_d(int n, const double *in, double *out);
+void orc_hc2r_d(int n, const double *in, double *out);
+
+/* raw2real::raw2realf/d, float formats without byte swap
+ * (brutefir/raw2real.cpp:52-55, 70-73, 258-261, 274-277). raw_bytes = 4 or 8. */
+void orc_raw2real_f(float *real, const void *raw, int raw_bytes, int spacing, int n);
+void orc_raw2real_d(double *real, const void *raw, int raw_bytes, int spacing, int n);
+
+/* convolver_raw2cbuf (brutefir/fftw_convolver.cpp:156-185). */
+void orc_raw2cbuf_f(int n_fft2, const void *raw, int byte_offset, int raw_bytes, int spacing,
+                    float *cbuf, float *next_cbuf);
+void orc_raw2cbuf_d(int n_fft2, const void *raw, int byte_offset, int raw_bytes, int spacing,
+                    double *cbuf, double *next_cbuf);
+
+/* mixnscale, n_bufs == 1 (brutefir/fftw_convolver.cpp:883-907, 1163-1186,
+ * 1583-1607, 1860-1883). */
+void orc_mixnscale_f(int n_fft, const float *in, float *out, double scale, int mixmode);
+void orc_mixnscale_d(int n_fft, const double *in, double *out, double scale, int mixmode);
+
+/* convolve_inplace / convolve / convolve_add
+ * (brutefir/fftw_convolver.cpp:1429-1525, 2125-2220). */
+void orc_convolve_inplace_f(int n_fft, float *cbuf, const float *coeffs);
+void orc_convolve_f(int n_fft, const float *in, const float *coeffs, float *out);
+void orc_convolve_add_f(int n_fft, const float *in, const float *coeffs, float *out);
+void orc_convolve_inplace_d(int n_fft, double *cbuf, const double *coeffs);
+void orc_convolve_d(int n_fft, const double *in, const double *coeffs, double *out);
+void orc_convolve_add_d(int n_fft, const double *in, const double *coeffs, double *out);
+
+/* convolver_coeffs2cbuf (brutefir/fftw_convolver.cpp:474-537): dest holds
+ * n_fft reals.  Returns 0, or -1 for a non-finite tap. */
+int orc_coeffs2cbuf_f(int n_fft2, const float *coeffs, int n_coeffs, double scale, float *dest);
+int orc_coeffs2cbuf_d(int n_fft2, const double *coeffs, int n_coeffs, double scale, double *dest);
+
+/* real2raw{f,d}_no_dither, float formats without byte swap
+ * (brutefir/real2raw.cpp:321-336, 365-420, 924-1016). */
+void orc_real2raw_f(void *raw, const float *real, int raw_bytes, int spacing, int n,
+                    orc_overflow_t *of);
+void orc_real2raw_d(void *raw, const double *real, int raw_bytes, int spacing, int n,
+                    orc_overflow_t *of);
+
+/* ---- engine level: brutefir::brutefir / set_coeff / run / reset ---- */
+typedef struct orc_engine orc_engine;
+
+/* brutefir::brutefir (brutefir/brutefir.cpp:21-44).  NULL if the arguments
+ * are rejected (realsize not 4/8, length not a power of two >= 4, channels
+ * outside 1..8, format not FLOAT_LE / FLOAT64_LE). */
+orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
+                              int in_format, int out_format);
+void orc_engine_destroy(orc_engine *e);
+
+/* brutefir::set_coeff(void**, ...) (brutefir/brutefir.cpp:179-228) with
+ * coeff::preprocess_coeff (brutefir/coeff.cpp:292-354).  0, or -2. */
+int orc_engine_set_coeff(orc_engine *e, const void *const *coeffs, int n_coeffs, int length,
+                         int coeff_blocks, double scale);
+
+/* brutefir::run (brutefir/brutefir.cpp:244-343): one block of filter_length
+ * interleaved frames.  0, or -1 on a non-finite first output sample. */
+int orc_engine_run(orc_engine *e, const void *inbuf, void *outbuf);
+
+/* n_blocks consecutive run() calls; stops at the first failure. */
+int orc_engine_run_blocks(orc_engine *e, const void *inbuf, void *outbuf, int n_blocks);
+
+/* brutefir::reset (brutefir/brutefir.cpp:346-367). */
+void orc_engine_reset(orc_engine *e);
+void orc_engine_get_overflow(const orc_engine *e, int channel, orc_overflow_t *of);
+/* Pointer to partition spectrum `block` of channel `ch` (n_fft reals). */
+const void *orc_engine_coeff_block(const orc_engine *e, int ch, int block);
+
+/* ---- independent checker (not a restatement of anything) ----
+ * Direct-form linear convolution in long double:
+ *   y[n] = sum_k h[k] x[n-k],  n < n_x,  x[<0] = 0.   Inputs/outputs double. */
+void orc_direct_conv(const double *x, int n_x, const double *h, int n_h, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

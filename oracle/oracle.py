@@ -1,0 +1,246 @@
+"""ctypes front end of the CPU oracle (oracle/bfir_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/bfir_oracle.h).
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libbfir_oracle.so")
+
+FMT_FLOAT_LE = 8      # brutefir/global.h:31
+FMT_FLOAT64_LE = 10   # brutefir/global.h:33
+MIXMODE_INPUT = 1     # brutefir/fftw_convolver.hpp:14
+MIXMODE_OUTPUT = 3    # brutefir/fftw_convolver.hpp:16
+
+
+class Overflow(C.Structure):
+    """bfoverflow_t, brutefir/global.h:96-102."""
+    _fields_ = [("n_overflows", C.c_uint), ("intlargest", C.c_int32),
+                ("largest", C.c_double), ("max", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (make -C oracle)."""
+    srcs = [os.path.join(_HERE, f) for f in
+            ("bfir_oracle.c", "bfir_oracle_impl.inc", "bfir_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+        sig = {
+            "orc_r2hc_f": (None, [ci, vp, vp]), "orc_hc2r_f": (None, [ci, vp, vp]),
+            "orc_r2hc_d": (None, [ci, vp, vp]), "orc_hc2r_d": (None, [ci, vp, vp]),
+            "orc_raw2real_f": (None, [vp, vp, ci, ci, ci]),
+            "orc_raw2real_d": (None, [vp, vp, ci, ci, ci]),
+            "orc_raw2cbuf_f": (None, [ci, vp, ci, ci, ci, vp, vp]),
+            "orc_raw2cbuf_d": (None, [ci, vp, ci, ci, ci, vp, vp]),
+            "orc_mixnscale_f": (None, [ci, vp, vp, cd, ci]),
+            "orc_mixnscale_d": (None, [ci, vp, vp, cd, ci]),
+            "orc_convolve_inplace_f": (None, [ci, vp, vp]),
+            "orc_convolve_inplace_d": (None, [ci, vp, vp]),
+            "orc_convolve_f": (None, [ci, vp, vp, vp]), "orc_convolve_d": (None, [ci, vp, vp, vp]),
+            "orc_convolve_add_f": (None, [ci, vp, vp, vp]),
+            "orc_convolve_add_d": (None, [ci, vp, vp, vp]),
+            "orc_coeffs2cbuf_f": (ci, [ci, vp, ci, cd, vp]),
+            "orc_coeffs2cbuf_d": (ci, [ci, vp, ci, cd, vp]),
+            "orc_real2raw_f": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
+            "orc_real2raw_d": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
+            "orc_engine_create": (vp, [ci, ci, ci, ci, ci, ci]),
+            "orc_engine_destroy": (None, [vp]),
+            "orc_engine_set_coeff": (ci, [vp, C.POINTER(vp), ci, ci, ci, cd]),
+            "orc_engine_run": (ci, [vp, vp, vp]),
+            "orc_engine_run_blocks": (ci, [vp, vp, vp, ci]),
+            "orc_engine_reset": (None, [vp]),
+            "orc_engine_get_overflow": (None, [vp, ci, C.POINTER(Overflow)]),
+            "orc_engine_coeff_block": (vp, [vp, ci, ci]),
+            "orc_direct_conv": (None, [vp, ci, vp, ci, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def real_dtype(realsize):
+    return np.float32 if realsize == 4 else np.float64
+
+
+def fmt_dtype(fmt):
+    return {FMT_FLOAT_LE: np.float32, FMT_FLOAT64_LE: np.float64}[fmt]
+
+
+def _suf(dtype):
+    return "_f" if np.dtype(dtype) == np.float32 else "_d"
+
+
+# ---- stage level ---------------------------------------------------------
+def r2hc(x):
+    x = np.ascontiguousarray(x)
+    out = np.empty_like(x)
+    getattr(lib(), "orc_r2hc" + _suf(x.dtype))(x.size, _p(x), _p(out))
+    return out
+
+
+def hc2r(x):
+    x = np.ascontiguousarray(x)
+    out = np.empty_like(x)
+    getattr(lib(), "orc_hc2r" + _suf(x.dtype))(x.size, _p(x), _p(out))
+    return out
+
+
+def mixnscale(x, scale, mixmode):
+    x = np.ascontiguousarray(x)
+    out = np.zeros_like(x)
+    getattr(lib(), "orc_mixnscale" + _suf(x.dtype))(x.size, _p(x), _p(out), float(scale), mixmode)
+    return out
+
+
+def convolve(b, c):
+    b, c = np.ascontiguousarray(b), np.ascontiguousarray(c)
+    d = np.empty_like(b)
+    getattr(lib(), "orc_convolve" + _suf(b.dtype))(b.size, _p(b), _p(c), _p(d))
+    return d
+
+
+def convolve_add(b, c, d):
+    b, c = np.ascontiguousarray(b), np.ascontiguousarray(c)
+    d = np.array(d, copy=True)
+    getattr(lib(), "orc_convolve_add" + _suf(b.dtype))(b.size, _p(b), _p(c), _p(d))
+    return d
+
+
+def convolve_inplace(b, c):
+    b, c = np.array(b, copy=True), np.ascontiguousarray(c)
+    getattr(lib(), "orc_convolve_inplace" + _suf(b.dtype))(b.size, _p(b), _p(c))
+    return b
+
+
+def coeffs2cbuf(taps, n_fft2, scale=1.0):
+    taps = np.ascontiguousarray(taps)
+    dest = np.zeros(2 * n_fft2, dtype=taps.dtype)
+    rc = getattr(lib(), "orc_coeffs2cbuf" + _suf(taps.dtype))(n_fft2, _p(taps), taps.size,
+                                                               float(scale), _p(dest))
+    return None if rc != 0 else dest
+
+
+def raw2cbuf(raw, channel, n_fft2, realsize, prev_next=None):
+    """raw: interleaved [frames, C] array (float32/float64). Returns (cbuf, next_cbuf)."""
+    raw = np.ascontiguousarray(raw)
+    rd = real_dtype(realsize)
+    cbuf = np.zeros(2 * n_fft2, dtype=rd)
+    if prev_next is not None:
+        cbuf[:n_fft2] = prev_next[:n_fft2]
+    nxt = np.zeros(2 * n_fft2, dtype=rd)
+    getattr(lib(), "orc_raw2cbuf" + _suf(rd))(n_fft2, _p(raw), channel * raw.itemsize,
+                                               raw.itemsize, raw.shape[1], _p(cbuf), _p(nxt))
+    return cbuf, nxt
+
+
+def real2raw(real, raw, channel, of):
+    """Scatter `real` into channel `channel` of interleaved `raw`, updating Overflow `of`."""
+    real = np.ascontiguousarray(real)
+    base = raw.ctypes.data + channel * raw.itemsize
+    getattr(lib(), "orc_real2raw" + _suf(real.dtype))(C.c_void_p(base), _p(real), raw.itemsize,
+                                                      raw.shape[1], real.size, C.byref(of))
+
+
+def direct_conv(x, h):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_direct_conv(_p(x), x.size, _p(h), h.size, _p(y))
+    return y
+
+
+# ---- engine level --------------------------------------------------------
+class Engine:
+    """brutefir (brutefir/brutefir.hpp:15-128) restated on the CPU."""
+
+    def __init__(self, filter_length, filter_blocks, realsize, channels,
+                 in_format=None, out_format=None):
+        dflt = FMT_FLOAT_LE if realsize == 4 else FMT_FLOAT64_LE
+        self.L, self.B, self.s, self.C = filter_length, filter_blocks, realsize, channels
+        self.in_format = dflt if in_format is None else in_format
+        self.out_format = dflt if out_format is None else out_format
+        self.h = lib().orc_engine_create(filter_length, filter_blocks, realsize, channels,
+                                         self.in_format, self.out_format)
+        if not self.h:
+            raise ValueError("oracle rejected engine parameters")
+
+    def close(self):
+        if self.h:
+            lib().orc_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_coeff(self, coeffs, coeff_blocks=None, scale=1.0, length=None):
+        """coeffs: sequence of 1-D tap arrays (one per channel), working precision."""
+        rd = real_dtype(self.s)
+        arrs = [np.ascontiguousarray(c, dtype=rd) for c in coeffs]
+        length = arrs[0].size if length is None else length
+        coeff_blocks = self.B if coeff_blocks is None else coeff_blocks
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        return lib().orc_engine_set_coeff(self.h, ptrs, len(arrs), length, coeff_blocks,
+                                          float(scale))
+
+    def run(self, x):
+        """x: [n_blocks*L, C] interleaved frames in the input format. Returns (rc, y)."""
+        x = np.ascontiguousarray(x, dtype=fmt_dtype(self.in_format))
+        assert x.ndim == 2 and x.shape[1] == self.C and x.shape[0] % self.L == 0
+        y = np.zeros(x.shape, dtype=fmt_dtype(self.out_format))
+        rc = lib().orc_engine_run_blocks(self.h, _p(x), _p(y), x.shape[0] // self.L)
+        return rc, y
+
+    def reset(self):
+        lib().orc_engine_reset(self.h)
+
+    def overflow(self, ch):
+        of = Overflow()
+        lib().orc_engine_get_overflow(self.h, ch, C.byref(of))
+        return of
+
+    def coeff_block(self, ch, block):
+        p = lib().orc_engine_coeff_block(self.h, ch, block)
+        n = 2 * self.L
+        buf = (C.c_char * (n * self.s)).from_address(p)
+        return np.frombuffer(buf, dtype=real_dtype(self.s), count=n).copy()
+
+
+# ---- synthetic workloads --------------------------
+def synth_ir(rng, channels, taps, dtype):
+    """uniform[-1,1) * exp(-6 n / taps), normalised so sum|h| <= 1 per channel."""
+    n = np.arange(taps, dtype=np.float64)
+    out = []
+    for _ in range(channels):
+        h = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n / taps)
+        h /= max(np.abs(h).sum(), 1e-30)
+        out.append(h.astype(dtype))
+    return out
+
+
+def synth_audio(rng, frames, channels, dtype):
+    """i.i.d. uniform [-1,1) like buffer::load_white_noise (brutefir/buffer.cpp:454-493)."""
+    return rng.uniform(-1.0, 1.0, (frames, channels)).astype(dtype)

@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's `fftw_convolver` class
+(brutefir/fftw_convolver.hpp:28-166) over the stage-level C ABI.  Buffers are
+numpy arrays in host memory, as the reference's are malloc'ed host blocks."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BfirError, BufferFormat, Overflow
+
+
+def make_buffer_format(fmt, channel, n_channels):
+    """setup_input / setup_output for a float format (brutefir/brutefir.cpp:512-582)."""
+    nbytes = {_lib.SAMPLE_FORMAT_FLOAT_LE: 4, _lib.SAMPLE_FORMAT_FLOAT64_LE: 8}[fmt]
+    bf = BufferFormat()
+    bf.sf.isfloat, bf.sf.swap = True, False
+    bf.sf.bytes = bf.sf.sbytes = nbytes
+    bf.sf.scale, bf.sf.format = 1.0, fmt
+    bf.sample_spacing, bf.byte_offset = n_channels, channel * nbytes
+    return bf
+
+
+class FftwConvolver:
+    """fftw_convolver(length, realsize, dither) -- the dither object is not
+    needed for float outputs and is not taken."""
+
+    def __init__(self, length, realsize, device=0):
+        self._lib = _lib.load()
+        self.n_fft2, self.n_fft, self.realsize = length, 2 * length, realsize
+        self.dtype = np.float32 if realsize == 4 else np.float64
+        err = C.c_int(0)
+        self._h = self._lib.bfir_convolver_create(length, realsize, device, C.byref(err))
+        if not self._h:
+            raise BfirError(err.value, "bfir_convolver_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bfir_convolver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise BfirError(rc, what)
+
+    def _buf(self, a):
+        assert a.dtype == self.dtype and a.flags.c_contiguous and a.size >= self.n_fft
+        return a.ctypes.data
+
+    def convolver_cbufsize(self):
+        return self._lib.bfir_convolver_cbufsize(self._h)
+
+    def new_cbuf(self):
+        return np.zeros(self.n_fft, dtype=self.dtype)
+
+    def convolver_raw2cbuf(self, rawbuf, cbuf, next_cbuf, bf):
+        self._chk(self._lib.bfir_convolver_raw2cbuf(self._h, rawbuf.ctypes.data, self._buf(cbuf),
+                                                    self._buf(next_cbuf), C.byref(bf)), "raw2cbuf")
+
+    def convolver_time2freq(self, input_cbuf, output_cbuf):
+        self._chk(self._lib.bfir_convolver_time2freq(self._h, self._buf(input_cbuf),
+                                                     self._buf(output_cbuf)), "time2freq")
+
+    def convolver_mixnscale(self, input_cbufs, output_cbuf, scales, n_bufs, mixmode):
+        ptrs = (C.c_void_p * n_bufs)(*[self._buf(b) for b in input_cbufs[:n_bufs]])
+        sc = (C.c_double * n_bufs)(*[float(v) for v in scales[:n_bufs]])
+        self._chk(self._lib.bfir_convolver_mixnscale(self._h, ptrs, self._buf(output_cbuf), sc, n_bufs,
+                                                     mixmode), "mixnscale")
+
+    def convolver_convolve_inplace(self, cbuf, coeffs):
+        self._chk(self._lib.bfir_convolver_convolve_inplace(self._h, self._buf(cbuf), self._buf(coeffs)),
+                  "convolve_inplace")
+
+    def convolver_convolve(self, input_cbuf, coeffs, output_cbuf):
+        self._chk(self._lib.bfir_convolver_convolve(self._h, self._buf(input_cbuf), self._buf(coeffs),
+                                                    self._buf(output_cbuf)), "convolve")
+
+    def convolver_convolve_add(self, input_cbuf, coeffs, output_cbuf):
+        self._chk(self._lib.bfir_convolver_convolve_add(self._h, self._buf(input_cbuf), self._buf(coeffs),
+                                                        self._buf(output_cbuf)), "convolve_add")
+
+    def convolver_freq2time(self, input_cbuf, output_cbuf):
+        self._chk(self._lib.bfir_convolver_freq2time(self._h, self._buf(input_cbuf),
+                                                     self._buf(output_cbuf)), "freq2time")
+
+    def convolver_cbuf2raw(self, cbuf, outbuf, bf, overflow):
+        self._chk(self._lib.bfir_convolver_cbuf2raw(self._h, self._buf(cbuf), outbuf.ctypes.data,
+                                                    C.byref(bf), C.byref(overflow)), "cbuf2raw")
+
+    def convolver_coeffs2cbuf(self, coeffs, n_coeffs, scale, optional_dest=None):
+        """Returns the spectrum as an array (optional_dest if given), or None
+        on a NaN/Inf tap (the reference returns NULL)."""
+        taps = np.ascontiguousarray(coeffs, dtype=self.dtype)
+        dest = self.new_cbuf() if optional_dest is None else optional_dest
+        p = self._lib.bfir_convolver_coeffs2cbuf(self._h, taps.ctypes.data, n_coeffs, float(scale),
+                                                 self._buf(dest))
+        return dest if p else None

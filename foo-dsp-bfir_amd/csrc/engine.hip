@@ -1,0 +1,638 @@
+// engine.hip -- host side of the fused engine: bfir_engine_* of include/bfir_hip.h.
+//
+// One bfir_engine reproduces n_eng independent `brutefir` instances
+// (brutefir/brutefir.hpp:15-128).  State the reference keeps in host memory
+// (brutefir.cpp:738-810) lives in HBM for the life of the engine:
+//   H     [GC][B][N]        partition spectra        (bfcoeff_t.data, coeff.cpp:292-354)
+//   X     [GC][R][N]        delay line of spectra    (cbuf[n][B]; R >= chunk+B-1 slots)
+//   Y     [GC][chunk][N]    accumulated spectra      (ocbuf[n])
+//   tin   [GC][(chunk+1)L]  planar time input, slot 0 = previous block (input_timecbuf)
+//   tout  [GC][chunk*L]     planar time output
+//   hist  [2][GC][L]        first halves of input_timecbuf[n][0/1]
+// GC = n_eng * C global channels.  A run of n blocks is cut into chunks of at
+// most `chunk` blocks; each chunk is five launches on one stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/bfir_hip.h"
+#include "kernels.h"
+
+using namespace bfir;
+
+// ---------------------------------------------------------------------------
+// logging (pinfo.c:17-39 shape) and errors
+// ---------------------------------------------------------------------------
+static bfir_log_fn g_log = nullptr;
+
+extern "C" void bfir_set_log_callback(bfir_log_fn fn) { g_log = fn; }
+
+void bfir_logf(const char *fmt, ...)
+{
+    if (!g_log) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_log(buf);
+}
+
+extern "C" const char *bfir_strerror(int err)
+{
+    switch (err) {
+    case BFIR_OK: return "ok";
+    case BFIR_ERR_NONFINITE: return "NaN or Inf values in the system";
+    case BFIR_ERR_COEFF: return "NaN or Inf value among coefficients";
+    case BFIR_ERR_ARG: return "invalid argument";
+    case BFIR_ERR_NO_DEVICE: return "no HIP device";
+    case BFIR_ERR_HIP: return "HIP runtime error";
+    case BFIR_ERR_STATE: return "engine not initialised";
+    case BFIR_ERR_UNSUPPORTED: return "unsupported format or size";
+    }
+    return "unknown error";
+}
+
+extern "C" int bfir_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *bfir_version(void) { return "bfir-hip 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            bfir_logf("HIP error %s at %s:%d", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return BFIR_ERR_HIP;                                                   \
+        }                                                                          \
+    } while (0)
+
+static int fmt_bytes(int fmt)
+{
+    // brutefir/brutefir.cpp:512-538 (FLOAT_LE, FLOAT64_LE: scale 1.0, no swap)
+    if (fmt == BFIR_SAMPLE_FORMAT_FLOAT_LE) return 4;
+    if (fmt == BFIR_SAMPLE_FORMAT_FLOAT64_LE) return 8;
+    return 0;
+}
+
+struct bfir_engine {
+    int device = 0;
+    int L = 0, N = 0, B = 0, s = 0, C = 0, n_eng = 1, GC = 0;
+    int in_bytes = 0, out_bytes = 0;
+    double in_scale = 1.0, out_scale = 1.0, of_max = 1.0;
+    FftPlan plan;
+    int chunk = 0, ring = 0;        // allocated geometry
+    int want_chunk = 64;
+    void *H = nullptr, *X = nullptr, *Y = nullptr, *tin = nullptr, *tout = nullptr, *hist = nullptr;
+    int *d_nblk = nullptr;
+    DevOverflow *d_of = nullptr;
+    int *d_bad = nullptr;
+    std::vector<int> nblk;          // host copy
+    std::vector<char> eng_init;     // per engine: coefficients set
+    unsigned long long blockcounter = 0;
+    int curbuf = 0;
+    bool bad_armed = false;
+    hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr;
+    // host-pointer path: pinned + device staging, double buffered
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+    void *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    size_t stage_bytes_in = 0, stage_bytes_out = 0;
+    // profiling
+    bool profiling = false;
+    struct Span { int k; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[BFIR_K_COUNT] = {0, 0, 0, 0, 0};
+    long prof_n[BFIR_K_COUNT] = {0, 0, 0, 0, 0};
+};
+
+static size_t cbuf_bytes(const bfir_engine *e) { return (size_t)e->N * (size_t)e->s; }
+
+static void free_work(bfir_engine *e)
+{
+    void **bufs[] = {&e->X, &e->Y, &e->tin, &e->tout};
+    for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    for (int i = 0; i < 2; i++) {
+        if (e->pin_in[i]) (void)hipHostFree(e->pin_in[i]);
+        if (e->pin_out[i]) (void)hipHostFree(e->pin_out[i]);
+        if (e->dev_in[i]) (void)hipFree(e->dev_in[i]);
+        if (e->dev_out[i]) (void)hipFree(e->dev_out[i]);
+        e->pin_in[i] = e->pin_out[i] = e->dev_in[i] = e->dev_out[i] = nullptr;
+    }
+    e->stage_bytes_in = e->stage_bytes_out = 0;
+    e->chunk = e->ring = 0;
+}
+
+// (Re)allocate the chunk-sized work buffers.  The delay line is carried over
+// slot by slot when the ring size changes.
+static int alloc_work(bfir_engine *e, int chunk)
+{
+    const size_t cb = cbuf_bytes(e);
+    const int ring = chunk + e->B;  // >= chunk + B - 1
+    void *X = nullptr, *Y = nullptr, *tin = nullptr, *tout = nullptr;
+    HIP_TRY(hipMalloc(&X, (size_t)e->GC * ring * cb));
+    HIP_TRY(hipMalloc(&Y, (size_t)e->GC * chunk * cb));
+    HIP_TRY(hipMalloc(&tin, (size_t)e->GC * (chunk + 1) * e->L * e->s));
+    HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
+    HIP_TRY(hipMemsetAsync(X, 0, (size_t)e->GC * ring * cb, e->stream));
+    HIP_TRY(hipMemsetAsync(tin, 0, (size_t)e->GC * (chunk + 1) * e->L * e->s, e->stream));
+    if (e->X) {
+        // keep the last B-1 spectra: absolute block j lives in slot j % ring
+        const int keep = (int)std::min<unsigned long long>(e->blockcounter, (unsigned long long)(e->B - 1));
+        for (int d = 1; d <= keep; d++) {
+            const unsigned long long j = e->blockcounter - d;
+            const size_t so = (size_t)(j % e->ring) * cb, dn = (size_t)(j % ring) * cb;
+            HIP_TRY(hipMemcpy2DAsync((char *)X + dn, (size_t)ring * cb, (char *)e->X + so,
+                                     (size_t)e->ring * cb, cb, e->GC, hipMemcpyDeviceToDevice, e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    free_work(e);
+    e->X = X; e->Y = Y; e->tin = tin; e->tout = tout;
+    e->chunk = chunk; e->ring = ring;
+    return BFIR_OK;
+}
+
+extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_length, int filter_blocks,
+                                                 int realsize, int channels, int in_format,
+                                                 int out_format, int sampling_rate, int apply_dither,
+                                                 int device, int *err)
+{
+    (void)sampling_rate;
+    int dummy;
+    if (!err) err = &dummy;
+    *err = BFIR_OK;
+    // brutefir.cpp:652 (channel limit), fftw_convolver.cpp:64-74 (realsize, length)
+    if (channels < 1 || channels > BFIR_MAXCHANNELS) {
+        bfir_logf("Number of channels (%d) exceeds limit (%d).", channels, BFIR_MAXCHANNELS);
+        *err = BFIR_ERR_ARG; return nullptr;
+    }
+    if (realsize != 4 && realsize != 8) { bfir_logf("Invalid real size %d.", realsize); *err = BFIR_ERR_ARG; return nullptr; }
+    if (filter_length < 1 || (filter_length & (filter_length - 1))) {
+        bfir_logf("Invalid length %d.", filter_length); *err = BFIR_ERR_ARG; return nullptr;
+    }
+    if (filter_blocks < 1 || n_engines < 1) { *err = BFIR_ERR_ARG; return nullptr; }
+    if (!fmt_bytes(in_format) || !fmt_bytes(out_format) || apply_dither) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
+    int ndev = bfir_device_count();
+    if (ndev <= 0) { *err = BFIR_ERR_NO_DEVICE; return nullptr; }
+    if (device < 0 || device >= ndev) { *err = BFIR_ERR_ARG; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { *err = BFIR_ERR_HIP; return nullptr; }
+
+    bfir_engine *e = new bfir_engine();
+    e->device = device;
+    e->L = filter_length; e->N = 2 * filter_length; e->B = filter_blocks; e->s = realsize;
+    e->C = channels; e->n_eng = n_engines; e->GC = n_engines * channels;
+    e->in_bytes = fmt_bytes(in_format); e->out_bytes = fmt_bytes(out_format);
+    e->nblk.assign(e->GC, 0);
+    e->eng_init.assign(n_engines, 0);
+    int rc = fft_plan_create(&e->plan, filter_length, realsize);
+    if (rc != 0) { *err = (rc == -1) ? BFIR_ERR_UNSUPPORTED : BFIR_ERR_HIP; delete e; return nullptr; }
+    auto fail = [&](int code) { *err = code; bfir_engine_destroy(e); return (bfir_engine *)nullptr; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
+    if (hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
+    if (hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
+    for (int i = 0; i < 2; i++) {
+        if (hipEventCreateWithFlags(&e->ev_h2d[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_comp[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_d2h[i], hipEventDisableTiming) != hipSuccess)
+            return fail(BFIR_ERR_HIP);
+    }
+    const size_t cb = cbuf_bytes(e);
+    if (hipMalloc(&e->H, (size_t)e->GC * e->B * cb) != hipSuccess ||
+        hipMalloc(&e->hist, (size_t)2 * e->GC * e->L * e->s) != hipSuccess ||
+        hipMalloc((void **)&e->d_nblk, sizeof(int) * e->GC) != hipSuccess ||
+        hipMalloc((void **)&e->d_of, sizeof(DevOverflow) * e->GC) != hipSuccess ||
+        hipMalloc((void **)&e->d_bad, sizeof(int)) != hipSuccess)
+        return fail(BFIR_ERR_HIP);
+    (void)hipMemset(e->H, 0, (size_t)e->GC * e->B * cb);
+    (void)hipMemset(e->hist, 0, (size_t)2 * e->GC * e->L * e->s);
+    (void)hipMemset(e->d_nblk, 0, sizeof(int) * e->GC);
+    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
+    (void)hipMemset(e->d_bad, 0x7f, sizeof(int));
+    if (alloc_work(e, 1) != BFIR_OK) return fail(BFIR_ERR_HIP);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(BFIR_ERR_HIP);
+    bfir_logf("bfir engine: %d x %d channels, partition %d, %d blocks, realsize %d on device %d.",
+              n_engines, channels, filter_length, filter_blocks, realsize, device);
+    return e;
+}
+
+extern "C" bfir_engine *bfir_engine_create(int filter_length, int filter_blocks, int realsize,
+                                           int channels, int in_format, int out_format,
+                                           int sampling_rate, int apply_dither, int device, int *err)
+{
+    return bfir_engine_create_batch(1, filter_length, filter_blocks, realsize, channels, in_format,
+                                    out_format, sampling_rate, apply_dither, device, err);
+}
+
+extern "C" void bfir_engine_destroy(bfir_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    free_work(e);
+    fft_plan_destroy(&e->plan);
+    void *bufs[] = {e->H, e->hist, e->d_nblk, e->d_of, e->d_bad};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (auto &sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; i++) {
+        if (e->ev_h2d[i]) (void)hipEventDestroy(e->ev_h2d[i]);
+        if (e->ev_comp[i]) (void)hipEventDestroy(e->ev_comp[i]);
+        if (e->ev_d2h[i]) (void)hipEventDestroy(e->ev_d2h[i]);
+    }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
+    delete e;
+}
+
+extern "C" int bfir_engine_is_initialized(const bfir_engine *e)
+{
+    if (!e) return 0;
+    for (char c : e->eng_init) if (!c) return 0;
+    return 1;
+}
+
+extern "C" int bfir_engine_set_chunk(bfir_engine *e, int blocks_per_launch)
+{
+    if (!e || blocks_per_launch < 1) return BFIR_ERR_ARG;
+    e->want_chunk = blocks_per_launch;
+    return BFIR_OK;
+}
+
+// coeff::preprocess_coeff + convolver_coeffs2cbuf for the C channels of one engine.
+extern "C" int bfir_engine_set_coeff_at(bfir_engine *e, int engine_index, const void *const *coeffs,
+                                        int n_coeffs, int length, int coeff_blocks, double scale)
+{
+    if (!e || engine_index < 0 || engine_index >= e->n_eng || !coeffs || length < 0 || coeff_blocks < 1)
+        return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->eng_init[engine_index] = 0;                              // free_coeff(), brutefir.cpp:188
+    if (n_coeffs > e->C) n_coeffs = e->C;                       // brutefir.cpp:190-193
+    const int nb = std::min(coeff_blocks, e->B);                // run() never looks past B blocks
+    const size_t taps_pad = (size_t)nb * e->L;
+    const size_t cb = cbuf_bytes(e);
+    const int gc0 = engine_index * e->C;
+    // zero padded impulse per channel; a block past the end is all zero
+    // (coeff.cpp:315-339), taps are scaled in working precision (fftw_convolver.cpp:491,507)
+    std::vector<char> host((size_t)e->C * taps_pad * e->s, 0);
+    for (int n = 0; n < n_coeffs; n++) {
+        if (!coeffs[n]) return BFIR_ERR_ARG;
+        const size_t cnt = std::min((size_t)length, taps_pad);
+        bool finite = true;
+        if (e->s == 4) {
+            const float *src = (const float *)coeffs[n];
+            const float sc = (float)scale;
+            for (size_t i = 0; i < cnt; i++) finite &= std::isfinite((double)(src[i] * sc));
+        } else {
+            const double *src = (const double *)coeffs[n];
+            for (size_t i = 0; i < cnt; i++) finite &= std::isfinite(src[i] * scale);
+        }
+        if (!finite) {
+            bfir_logf("NaN or Inf value among coefficients.");
+            bfir_logf("Error preprocessing coefficient %d", n);
+            return BFIR_ERR_COEFF;
+        }
+        memcpy(host.data() + (size_t)n * taps_pad * e->s, coeffs[n], cnt * e->s);
+    }
+    void *d_taps = nullptr;
+    HIP_TRY(hipMalloc(&d_taps, host.size()));
+    HIP_TRY(hipMemcpyAsync(d_taps, host.data(), host.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync((char *)e->H + (size_t)gc0 * e->B * cb, 0, (size_t)e->C * e->B * cb, e->stream));
+    FwdArgs fa;
+    // window of block b = [L zeros | taps b*L .. b*L+L): start the window L before the block
+    fa.src = (const char *)d_taps - (size_t)e->L * e->s;
+    fa.src_ch_stride = (long)taps_pad;
+    fa.dst = (char *)e->H + (size_t)gc0 * e->B * cb;
+    fa.dst_ch_stride = (long)e->B * e->N;
+    fa.ring = e->B; fa.base_slot = 0;
+    fa.n_t = nb; fa.n_ch = e->C;
+    fa.load_scale = scale;
+    fa.out_scale = 1.0 / (double)e->N;                          // fftw_convolver.cpp:520
+    fa.zero_first_half = 1;
+    launch_fwd(e->plan, fa, e->stream);
+    for (int n = 0; n < e->C; n++) e->nblk[gc0 + n] = nb;
+    HIP_TRY(hipMemcpyAsync(e->d_nblk + gc0, e->nblk.data() + gc0, sizeof(int) * e->C,
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(d_taps));
+    HIP_TRY(hipGetLastError());
+    e->eng_init[engine_index] = 1;
+    return BFIR_OK;
+}
+
+extern "C" int bfir_engine_set_coeff(bfir_engine *e, const void *const *coeffs, int n_coeffs,
+                                     int length, int coeff_blocks, double scale)
+{
+    return bfir_engine_set_coeff_at(e, 0, coeffs, n_coeffs, length, coeff_blocks, scale);
+}
+
+extern "C" int bfir_engine_read_coeff(bfir_engine *e, int channel, int block, void *dst)
+{
+    if (!e || channel < 0 || channel >= e->GC || block < 0 || block >= e->B || !dst) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t cb = cbuf_bytes(e);
+    HIP_TRY(hipMemcpy(dst, (char *)e->H + ((size_t)channel * e->B + block) * cb, cb, hipMemcpyDeviceToHost));
+    return BFIR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------
+static hipEvent_t take_event(bfir_engine *e)
+{
+    if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct ProfScope {
+    bfir_engine *e; int k; hipStream_t st; hipEvent_t a = nullptr;
+    ProfScope(bfir_engine *e_, int k_, hipStream_t st_) : e(e_), k(k_), st(st_)
+    {
+        if (e->profiling) { a = take_event(e); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope()
+    {
+        if (e->profiling) {
+            hipEvent_t b = take_event(e);
+            (void)hipEventRecord(b, st);
+            e->spans.push_back({k, a, b});
+        }
+    }
+};
+
+static void drain_spans(bfir_engine *e)
+{
+    for (auto &sp : e->spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            e->prof_ms[sp.k] += ms;
+            e->prof_n[sp.k] += 1;
+        }
+        e->ev_pool.push_back(sp.a);
+        e->ev_pool.push_back(sp.b);
+    }
+    e->spans.clear();
+}
+
+extern "C" int bfir_engine_set_profiling(bfir_engine *e, int enable)
+{
+    if (!e) return BFIR_ERR_ARG;
+    drain_spans(e);
+    e->profiling = enable != 0;
+    for (int k = 0; k < BFIR_K_COUNT; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
+    return BFIR_OK;
+}
+
+extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total_ms, long *launches)
+{
+    if (!e || kernel < 0 || kernel >= BFIR_K_COUNT) return BFIR_ERR_ARG;
+    drain_spans(e);
+    if (total_ms) *total_ms = e->prof_ms[kernel];
+    if (launches) *launches = e->prof_n[kernel];
+    return BFIR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// brutefir::run, chunked
+// ---------------------------------------------------------------------------
+// Queue one chunk of tc blocks (frames frame_off .. of every engine's raw buffer).
+static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
+                     long frame_off, int tc, int block_base, hipStream_t st)
+{
+    const size_t Ls = (size_t)e->L * e->s;
+    const long tin_stride = (long)(e->chunk + 1) * e->L, tout_stride = (long)e->chunk * e->L;
+    const size_t hist_plane = (size_t)e->GC * Ls;
+    // previous block as the reference sees it: first half of input_timecbuf[n][curbuf]
+    // (fftw_convolver.cpp:184 leaves it there one call earlier)
+    HIP_TRY(hipMemcpy2DAsync(e->tin, (size_t)tin_stride * e->s, (char *)e->hist + e->curbuf * hist_plane,
+                             Ls, Ls, e->GC, hipMemcpyDeviceToDevice, st));
+    {
+        ProfScope ps(e, BFIR_K_STAGE_IN, st);
+        StageInArgs a;
+        a.raw = d_in; a.eng_stride_bytes = in_stride; a.frame_off = frame_off;
+        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->in_bytes; a.spacing = e->C;
+        a.n_frames = (long)tc * e->L;
+        a.dst = e->tin; a.dst_ch_stride = tin_stride; a.dst_off = e->L;
+        a.realsize = e->s;
+        launch_stage_in(a, st);
+    }
+    const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
+    {
+        ProfScope ps(e, BFIR_K_FWD, st);
+        FwdArgs a;
+        a.src = e->tin; a.src_ch_stride = tin_stride;
+        a.dst = e->X; a.dst_ch_stride = (long)e->ring * e->N;
+        a.ring = e->ring; a.base_slot = base_slot;
+        a.n_t = tc; a.n_ch = e->GC;
+        a.load_scale = 1.0; a.out_scale = e->in_scale;
+        a.zero_first_half = 0;
+        launch_fwd(e->plan, a, st);
+    }
+    {
+        ProfScope ps(e, BFIR_K_MAC, st);
+        MacArgs a;
+        a.x = e->X; a.x_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
+        a.h = e->H; a.h_ch_stride = (long)e->B * e->N;
+        a.nblk = e->d_nblk;
+        a.y = e->Y; a.y_ch_stride = (long)e->chunk * e->N;
+        a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s;
+        launch_mac(a, st);
+    }
+    {
+        ProfScope ps(e, BFIR_K_INV, st);
+        InvArgs a;
+        a.src = e->Y; a.src_ch_stride = (long)e->chunk * e->N;
+        a.dst = e->tout; a.dst_ch_stride = tout_stride;
+        a.n_t = tc; a.n_ch = e->GC;
+        a.in_scale = e->out_scale;
+        a.full_output = 0;
+        launch_inv(e->plan, a, st);
+    }
+    {
+        ProfScope ps(e, BFIR_K_STAGE_OUT, st);
+        StageOutArgs a;
+        a.raw = d_out; a.eng_stride_bytes = out_stride; a.frame_off = frame_off;
+        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->out_bytes; a.spacing = e->C;
+        a.n_frames = (long)tc * e->L;
+        a.src = e->tout; a.src_ch_stride = tout_stride;
+        a.realsize = e->s; a.L = e->L; a.max = e->of_max;
+        a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        launch_stage_out(a, st);
+    }
+    // input_timecbuf bookkeeping: block j of the chunk is written into buffer
+    // !(curbuf ^ (j & 1)); keep the last two blocks where the reference has them.
+    const int idx_last = 1 ^ e->curbuf ^ ((tc - 1) & 1);
+    if (tc >= 2)
+        HIP_TRY(hipMemcpy2DAsync((char *)e->hist + (1 ^ idx_last) * hist_plane, Ls,
+                                 (char *)e->tin + (size_t)(tc - 1) * Ls, (size_t)tin_stride * e->s, Ls,
+                                 e->GC, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync((char *)e->hist + idx_last * hist_plane, Ls, (char *)e->tin + (size_t)tc * Ls,
+                             (size_t)tin_stride * e->s, Ls, e->GC, hipMemcpyDeviceToDevice, st));
+    e->curbuf ^= (tc & 1);
+    e->blockcounter += (unsigned long long)tc;
+    return BFIR_OK;
+}
+
+static int ensure_chunk(bfir_engine *e, int n_blocks)
+{
+    const int want = std::max(1, std::min(e->want_chunk, n_blocks));
+    if (want > e->chunk) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return alloc_work(e, want);
+    }
+    return BFIR_OK;
+}
+
+extern "C" int bfir_engine_run_device(bfir_engine *e, const void *d_in, long in_stride_bytes,
+                                      void *d_out, long out_stride_bytes, int n_blocks, void *hip_stream)
+{
+    if (!e || !d_in || !d_out || n_blocks < 0) return BFIR_ERR_ARG;
+    if (!bfir_engine_is_initialized(e)) return BFIR_ERR_STATE;
+    if (n_blocks == 0) return BFIR_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    int rc = ensure_chunk(e, n_blocks);
+    if (rc != BFIR_OK) return rc;
+    for (int c0 = 0; c0 < n_blocks; c0 += e->chunk) {
+        const int tc = std::min(e->chunk, n_blocks - c0);
+        rc = run_chunk(e, d_in, in_stride_bytes, d_out, out_stride_bytes, (long)c0 * e->L, tc, c0, st);
+        if (rc != BFIR_OK) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return BFIR_OK;
+}
+
+extern "C" int bfir_engine_sync(bfir_engine *e)
+{
+    if (!e) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    drain_spans(e);
+    int bad = INT_MAX;
+    HIP_TRY(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad != 0x7f7f7f7f) {
+        HIP_TRY(hipMemset(e->d_bad, 0x7f, sizeof(int)));
+        bfir_logf("NaN or Inf values in the system! Invalid input? Aborting.\n");
+        return BFIR_ERR_NONFINITE;
+    }
+    return BFIR_OK;
+}
+
+static int ensure_staging(bfir_engine *e)
+{
+    const size_t bin = (size_t)e->n_eng * e->chunk * e->L * e->C * e->in_bytes;
+    const size_t bout = (size_t)e->n_eng * e->chunk * e->L * e->C * e->out_bytes;
+    if (e->stage_bytes_in >= bin && e->stage_bytes_out >= bout) return BFIR_OK;
+    for (int i = 0; i < 2; i++) {
+        if (e->pin_in[i]) (void)hipHostFree(e->pin_in[i]);
+        if (e->pin_out[i]) (void)hipHostFree(e->pin_out[i]);
+        if (e->dev_in[i]) (void)hipFree(e->dev_in[i]);
+        if (e->dev_out[i]) (void)hipFree(e->dev_out[i]);
+        e->pin_in[i] = e->pin_out[i] = e->dev_in[i] = e->dev_out[i] = nullptr;
+        HIP_TRY(hipHostMalloc(&e->pin_in[i], bin, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&e->pin_out[i], bout, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&e->dev_in[i], bin));
+        HIP_TRY(hipMalloc(&e->dev_out[i], bout));
+    }
+    e->stage_bytes_in = bin; e->stage_bytes_out = bout;
+    return BFIR_OK;
+}
+
+// Host-pointer run: pinned double buffers, H2D on s_in, kernels on stream,
+// D2H on s_out, so the copies of neighbouring chunks overlap the compute.
+extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, int n_blocks)
+{
+    if (!e || !inbuf || !outbuf || n_blocks < 0) return BFIR_ERR_ARG;
+    if (!bfir_engine_is_initialized(e)) return BFIR_ERR_STATE;
+    if (n_blocks == 0) return BFIR_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_chunk(e, n_blocks);
+    if (rc != BFIR_OK) return rc;
+    rc = ensure_staging(e);
+    if (rc != BFIR_OK) return rc;
+    const size_t fin = (size_t)e->C * e->in_bytes, fout = (size_t)e->C * e->out_bytes;  // bytes per frame
+    const size_t eng_in = (size_t)n_blocks * e->L * fin, eng_out = (size_t)n_blocks * e->L * fout;
+    const int nchunks = (n_blocks + e->chunk - 1) / e->chunk;
+    auto copy_out = [&](int k) -> int {
+        const int b = k & 1, c0 = k * e->chunk, tc = std::min(e->chunk, n_blocks - c0);
+        HIP_TRY(hipEventSynchronize(e->ev_d2h[b]));
+        const size_t per = (size_t)tc * e->L * fout;
+        for (int g = 0; g < e->n_eng; g++)
+            memcpy((char *)outbuf + g * eng_out + (size_t)c0 * e->L * fout, (char *)e->pin_out[b] + g * per, per);
+        return BFIR_OK;
+    };
+    for (int k = 0; k < nchunks; k++) {
+        const int b = k & 1, c0 = k * e->chunk, tc = std::min(e->chunk, n_blocks - c0);
+        if (k >= 2) { rc = copy_out(k - 2); if (rc != BFIR_OK) return rc; }
+        const size_t per_in = (size_t)tc * e->L * fin, per_out = (size_t)tc * e->L * fout;
+        for (int g = 0; g < e->n_eng; g++)
+            memcpy((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
+        HIP_TRY(hipMemcpyAsync(e->dev_in[b], e->pin_in[b], per_in * e->n_eng, hipMemcpyHostToDevice, e->s_in));
+        HIP_TRY(hipEventRecord(e->ev_h2d[b], e->s_in));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+        rc = run_chunk(e, e->dev_in[b], (long)per_in, e->dev_out[b], (long)per_out, 0, tc, c0, e->stream);
+        if (rc != BFIR_OK) return rc;
+        HIP_TRY(hipEventRecord(e->ev_comp[b], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
+        HIP_TRY(hipMemcpyAsync(e->pin_out[b], e->dev_out[b], per_out * e->n_eng, hipMemcpyDeviceToHost, e->s_out));
+        HIP_TRY(hipEventRecord(e->ev_d2h[b], e->s_out));
+        // the next H2D into dev_in[b] must not overtake this chunk's kernels
+        HIP_TRY(hipStreamWaitEvent(e->s_in, e->ev_comp[b], 0));
+    }
+    for (int k = std::max(0, nchunks - 2); k < nchunks; k++) { rc = copy_out(k); if (rc != BFIR_OK) return rc; }
+    return bfir_engine_sync(e);
+}
+
+extern "C" void bfir_engine_reset(bfir_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    // brutefir.cpp:346-367: counters only.  procblocks = 0 hides every
+    // delay-line slot written before the reset (brutefir.cpp:292), which the
+    // zeroed ring reproduces; the time-domain history is NOT cleared.
+    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
+    (void)hipMemset(e->X, 0, (size_t)e->GC * e->ring * cbuf_bytes(e));
+    e->blockcounter = 0;
+    e->curbuf = 0;
+}
+
+extern "C" int bfir_engine_get_overflow(bfir_engine *e, int channel, bfir_overflow *of)
+{
+    if (!e || !of || channel < 0 || channel >= e->GC) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    DevOverflow d;
+    HIP_TRY(hipMemcpy(&d, e->d_of + channel, sizeof(d), hipMemcpyDeviceToHost));
+    of->n_overflows = d.n_overflows;
+    of->intlargest = 0;
+    if (e->s == 4) {
+        unsigned int u = (unsigned int)d.largest_bits;
+        float f;
+        memcpy(&f, &u, sizeof(f));
+        of->largest = (double)f;
+    } else {
+        double f;
+        memcpy(&f, &d.largest_bits, sizeof(f));
+        of->largest = f;
+    }
+    of->max = e->of_max;
+    return BFIR_OK;
+}

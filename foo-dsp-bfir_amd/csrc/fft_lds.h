@@ -1,0 +1,269 @@
+// fft_lds.h -- workgroup-resident Stockham FFT for CDNA4 (gfx950), device side.
+//
+// One workgroup transforms one sequence of M = 2^LOG2M complex points that
+// lives in registers (P = M / NT points per thread) and is exchanged between
+// passes through ONE LDS buffer of M complex values.  This is the arithmetic
+// that replaces the reference's FFTW r2r plans
+// (brutefir/fftw_convolver.cpp:204-209 R2HC, :367-372 HC2R, plan creation
+// :798-806); the real<->half-complex split steps live in kernels.hip.
+//
+// Pass s (radix R, p = product of the radices before it), butterfly i < M/R:
+//     k      = i mod p
+//     u[r]   = x[i + r*M/R] * exp(-+2 pi i r k / (p R))       r < R
+//     v      = DFT_R(u)
+//     y[(i-k) R + k + q p] = v[q]                              q < R
+// After the last pass y is in natural order (Stockham autosort, no bit
+// reversal).  Twiddles come from a per-plan table built on the host in
+// double precision (see FftPlanHost in kernels.hip): tw[off(s) + (r-1) p + k].
+//
+// LDS layout: logical index i is stored at i ^ ((i >> 4) & 15).  With 8-byte
+// (float2) or 16-byte (double2) elements this makes the stride-R writes of
+// the first pass, the 16-runs of the second and every unit-stride read
+// conflict-free on gfx950's 64-bank LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bfir {
+
+template <typename T> struct Vec2;
+template <> struct Vec2<float>  { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+template <typename T> struct Vec4;
+template <> struct Vec4<float>  { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+// Threads per transform and radix sequence per size.  P = M / NT points per
+// thread; every radix divides P.
+template <int LOG2M> struct FftCfg;
+#define BFIR_FFT_CFG(lg, nt, np, a, b, c, d)                                   \
+    template <> struct FftCfg<lg> {                                            \
+        static constexpr int NT = nt, NP = np, R0 = a, R1 = b, R2 = c, R3 = d; \
+    };
+BFIR_FFT_CFG(4, 4, 2, 4, 4, 1, 1)
+BFIR_FFT_CFG(5, 4, 2, 8, 4, 1, 1)
+BFIR_FFT_CFG(6, 8, 2, 8, 8, 1, 1)
+BFIR_FFT_CFG(7, 16, 3, 8, 4, 4, 1)
+BFIR_FFT_CFG(8, 16, 2, 16, 16, 1, 1)
+BFIR_FFT_CFG(9, 32, 3, 16, 8, 4, 1)
+BFIR_FFT_CFG(10, 64, 3, 16, 16, 4, 1)
+BFIR_FFT_CFG(11, 128, 3, 16, 16, 8, 1)
+BFIR_FFT_CFG(12, 256, 3, 16, 16, 16, 1)
+BFIR_FFT_CFG(13, 512, 4, 16, 16, 8, 4)
+BFIR_FFT_CFG(14, 1024, 4, 16, 16, 16, 4)
+#undef BFIR_FFT_CFG
+
+constexpr int BFIR_MIN_LOG2M = 4;
+constexpr int BFIR_MAX_LOG2M = 14;
+
+// ---- small complex helpers on split re/im registers -----------------------
+template <typename T>
+__device__ __forceinline__ void cmul(T &re, T &im, T wr, T wi)
+{
+    T tr = re * wr - im * wi;
+    T ti = re * wi + im * wr;
+    re = tr; im = ti;
+}
+
+// multiply by exp(SIGN * 2 pi i m / 16)  (SIGN = -1 forward, +1 inverse)
+template <int MM, int SIGN, typename T>
+__device__ __forceinline__ void mul_w16(T &re, T &im)
+{
+    constexpr int m = ((MM % 16) + 16) % 16;
+    constexpr double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173,
+                     RH = 0.70710678118654752440;
+    constexpr double cs[16] = {1, C1, RH, S1, 0, -S1, -RH, -C1, -1, -C1, -RH, -S1, 0, S1, RH, C1};
+    constexpr double sn[16] = {0, S1, RH, C1, 1, C1, RH, S1, 0, -S1, -RH, -C1, -1, -C1, -RH, -S1};
+    if constexpr (m == 0) {
+    } else if constexpr (m == 8) {
+        re = -re; im = -im;
+    } else if constexpr (m == 4) {          // exp(SIGN i pi/2) = SIGN * i
+        T t = re;
+        if constexpr (SIGN < 0) { re = im; im = -t; } else { re = -im; im = t; }
+    } else if constexpr (m == 12) {         // -SIGN * i
+        T t = re;
+        if constexpr (SIGN < 0) { re = -im; im = t; } else { re = im; im = -t; }
+    } else {
+        cmul(re, im, (T)cs[m], (T)(SIGN * sn[m]));
+    }
+}
+
+template <int R, int SIGN, typename T> struct Dft;
+
+template <int SIGN, typename T> struct Dft<2, SIGN, T> {
+    __device__ __forceinline__ static void run(T *re, T *im)
+    {
+        T ar = re[0], ai = im[0];
+        re[0] = ar + re[1]; im[0] = ai + im[1];
+        re[1] = ar - re[1]; im[1] = ai - im[1];
+    }
+};
+
+template <int SIGN, typename T> struct Dft<4, SIGN, T> {
+    // stride lets the radix-8/16 kernels run it on interleaved sub-sequences
+    template <int STRIDE = 1>
+    __device__ __forceinline__ static void run(T *re, T *im)
+    {
+        T s0r = re[0] + re[2 * STRIDE], s0i = im[0] + im[2 * STRIDE];
+        T d0r = re[0] - re[2 * STRIDE], d0i = im[0] - im[2 * STRIDE];
+        T s1r = re[STRIDE] + re[3 * STRIDE], s1i = im[STRIDE] + im[3 * STRIDE];
+        T d1r = re[STRIDE] - re[3 * STRIDE], d1i = im[STRIDE] - im[3 * STRIDE];
+        re[0] = s0r + s1r;          im[0] = s0i + s1i;
+        re[2 * STRIDE] = s0r - s1r; im[2 * STRIDE] = s0i - s1i;
+        if constexpr (SIGN < 0) {   // X1 = d0 - i d1, X3 = d0 + i d1
+            re[STRIDE] = d0r + d1i;     im[STRIDE] = d0i - d1r;
+            re[3 * STRIDE] = d0r - d1i; im[3 * STRIDE] = d0i + d1r;
+        } else {
+            re[STRIDE] = d0r - d1i;     im[STRIDE] = d0i + d1r;
+            re[3 * STRIDE] = d0r + d1i; im[3 * STRIDE] = d0i - d1r;
+        }
+    }
+};
+
+// 8 = 4 x 2:  r = 2 r1 + r2,  q = q1 + 4 q2
+template <int SIGN, typename T> struct Dft<8, SIGN, T> {
+    __device__ __forceinline__ static void run(T *re, T *im)
+    {
+        Dft<4, SIGN, T>::template run<2>(re, im);          // r2 = 0: elements 0,2,4,6
+        Dft<4, SIGN, T>::template run<2>(re + 1, im + 1);  // r2 = 1: elements 1,3,5,7
+        // t[r2][q1] sits at 2 q1 + r2; twiddle w8^{q1} on r2 = 1
+        mul_w16<2, SIGN>(re[3], im[3]);
+        mul_w16<4, SIGN>(re[5], im[5]);
+        mul_w16<6, SIGN>(re[7], im[7]);
+        T xr[8], xi[8];
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) {
+            xr[q1] = re[2 * q1] + re[2 * q1 + 1];     xi[q1] = im[2 * q1] + im[2 * q1 + 1];
+            xr[q1 + 4] = re[2 * q1] - re[2 * q1 + 1]; xi[q1 + 4] = im[2 * q1] - im[2 * q1 + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { re[j] = xr[j]; im[j] = xi[j]; }
+    }
+};
+
+// 16 = 4 x 4:  r = 4 r1 + r2,  q = q1 + 4 q2
+template <int SIGN, typename T> struct Dft<16, SIGN, T> {
+    __device__ __forceinline__ static void run(T *re, T *im)
+    {
+        // step 1: for each r2, 4-point DFT over r1 (elements r2, r2+4, r2+8, r2+12):
+        // result t[r2][q1] lands at 4 q1 + r2
+        Dft<4, SIGN, T>::template run<4>(re, im);
+        Dft<4, SIGN, T>::template run<4>(re + 1, im + 1);
+        Dft<4, SIGN, T>::template run<4>(re + 2, im + 2);
+        Dft<4, SIGN, T>::template run<4>(re + 3, im + 3);
+        // step 2: t[r2][q1] *= w16^{r2 q1}
+        mul_w16<1, SIGN>(re[5], im[5]);   mul_w16<2, SIGN>(re[6], im[6]);   mul_w16<3, SIGN>(re[7], im[7]);
+        mul_w16<2, SIGN>(re[9], im[9]);   mul_w16<4, SIGN>(re[10], im[10]); mul_w16<6, SIGN>(re[11], im[11]);
+        mul_w16<3, SIGN>(re[13], im[13]); mul_w16<6, SIGN>(re[14], im[14]); mul_w16<9, SIGN>(re[15], im[15]);
+        // step 3: for each q1, 4-point DFT over r2 (contiguous 4 q1 .. 4 q1 + 3):
+        // X[q1 + 4 q2] lands at 4 q1 + q2  -> transpose to natural order
+        Dft<4, SIGN, T>::template run<1>(re, im);
+        Dft<4, SIGN, T>::template run<1>(re + 4, im + 4);
+        Dft<4, SIGN, T>::template run<1>(re + 8, im + 8);
+        Dft<4, SIGN, T>::template run<1>(re + 12, im + 12);
+        T xr[16], xi[16];
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++)
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++) { xr[q1 + 4 * q2] = re[4 * q1 + q2]; xi[q1 + 4 * q2] = im[4 * q1 + q2]; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { re[j] = xr[j]; im[j] = xi[j]; }
+    }
+};
+
+// ---- the workgroup transform ------------------------------------------------
+template <typename T, int LOG2M, int SIGN> struct LdsFft {
+    using Cfg = FftCfg<LOG2M>;
+    using V2 = typename Vec2<T>::type;
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int NT = Cfg::NT;
+    static constexpr int P = M / NT;
+    static constexpr int NP = Cfg::NP;
+
+    __host__ __device__ static constexpr int radix(int s)
+    {
+        return s == 0 ? Cfg::R0 : s == 1 ? Cfg::R1 : s == 2 ? Cfg::R2 : Cfg::R3;
+    }
+    __host__ __device__ static constexpr int pprod(int s)
+    {
+        int p = 1;
+        for (int j = 0; j < s; j++) p *= radix(j);
+        return p;
+    }
+    // offset of pass s in the twiddle table (pass 0 needs none)
+    __host__ __device__ static constexpr int twoff(int s)
+    {
+        int o = 0;
+        for (int j = 1; j < s; j++) o += (radix(j) - 1) * pprod(j);
+        return o;
+    }
+    __host__ __device__ static constexpr int twsize() { return twoff(NP); }
+
+    __device__ __forceinline__ static int phys(int i) { return i ^ ((i >> 4) & 15); }
+
+    // logical index held in register slot e before pass 0
+    __device__ __forceinline__ static int in_index(int tid, int e)
+    {
+        constexpr int R = radix(0);
+        return (tid + (e / R) * NT) + (e % R) * (M / R);
+    }
+    // logical index held in register slot e after the last pass
+    __device__ __forceinline__ static int out_index(int tid, int e)
+    {
+        constexpr int R = radix(NP - 1);
+        return (tid + (e / R) * NT) + (e % R) * (M / R);
+    }
+
+    template <int S>
+    __device__ __forceinline__ static void butterflies(T *re, T *im, const V2 *__restrict__ tw, int tid)
+    {
+        constexpr int R = radix(S), p = pprod(S);
+#pragma unroll
+        for (int b = 0; b < P / R; b++) {
+            if constexpr (p > 1) {
+                const int k = (tid + b * NT) & (p - 1);
+#pragma unroll
+                for (int r = 1; r < R; r++) {
+                    V2 w = tw[twoff(S) + (r - 1) * p + k];
+                    cmul(re[b * R + r], im[b * R + r], w.x, (T)(SIGN < 0 ? w.y : -w.y));
+                }
+            }
+            Dft<R, SIGN, T>::run(re + b * R, im + b * R);
+        }
+    }
+
+    // write the outputs of pass S to LDS and fetch the inputs of pass S+1
+    template <int S>
+    __device__ __forceinline__ static void exchange(T *re, T *im, V2 *lds, int tid)
+    {
+        constexpr int R = radix(S), p = pprod(S), Rn = radix(S + 1);
+        __syncthreads();  // earlier readers of lds are done
+#pragma unroll
+        for (int b = 0; b < P / R; b++) {
+            const int i = tid + b * NT, k = i & (p - 1);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                V2 v; v.x = re[b * R + q]; v.y = im[b * R + q];
+                lds[phys((i - k) * R + k + q * p)] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < P / Rn; b++)
+#pragma unroll
+            for (int r = 0; r < Rn; r++) {
+                V2 v = lds[phys((tid + b * NT) + r * (M / Rn))];
+                re[b * Rn + r] = v.x; im[b * Rn + r] = v.y;
+            }
+    }
+
+    // Full transform of the P register points (in_index order in, out_index order out).
+    __device__ __forceinline__ static void run(T *re, T *im, V2 *lds, const V2 *__restrict__ tw, int tid)
+    {
+        butterflies<0>(re, im, tw, tid);
+        if constexpr (NP > 1) { exchange<0>(re, im, lds, tid); butterflies<1>(re, im, tw, tid); }
+        if constexpr (NP > 2) { exchange<1>(re, im, lds, tid); butterflies<2>(re, im, tw, tid); }
+        if constexpr (NP > 3) { exchange<2>(re, im, lds, tid); butterflies<3>(re, im, tw, tid); }
+    }
+};
+
+}  // namespace bfir

@@ -1,0 +1,102 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal API,
+// C++; the public C ABI is include/bfir_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bfir {
+
+// Per-channel output statistics kept on the device; folded into
+// bfoverflow_t (brutefir/global.h:96-102) by the host.
+struct DevOverflow {
+    unsigned int n_overflows;          // samples with |y| > max
+    unsigned int pad;
+    unsigned long long largest_bits;   // bit pattern of max |y| (float widened, or double)
+};
+
+// Twiddle tables of one transform size / precision, resident in HBM.
+struct FftPlan {
+    int log2m = 0;        // M = L complex points; N = 2M reals
+    int realsize = 0;     // 4 or 8
+    void *tw = nullptr;   // per-pass twiddles  exp(-2 pi i r k / (p R))
+    void *ws = nullptr;   // split twiddles     exp(-2 pi i k / N), k < M
+};
+
+int  fft_plan_create(FftPlan *plan, int filter_length, int realsize);   // 0 or negative error
+void fft_plan_destroy(FftPlan *plan);
+int  fft_threads(int log2m);
+
+// a5: interleaved raw frames -> planar working-precision time buffers.
+// Engine e reads frames frame_off .. frame_off+n_frames-1 of the interleaved
+// buffer at raw + e*eng_stride_bytes.  dst[gc][dst_off + f], gc = e*C + c.
+struct StageInArgs {
+    const void *raw; long eng_stride_bytes; long frame_off;
+    int n_eng, C, raw_bytes;       // raw_bytes 4 (FLOAT_LE) or 8 (FLOAT64_LE)
+    int spacing;                   // samples between frames (buffer_format_t.sample_spacing)
+    long n_frames;
+    void *dst; long dst_ch_stride; long dst_off;   // in reals
+    int realsize;
+};
+void launch_stage_in(const StageInArgs &a, hipStream_t s);
+
+// a13: planar time -> interleaved raw frames + overflow statistics + NaN guard.
+struct StageOutArgs {
+    void *raw; long eng_stride_bytes; long frame_off;
+    int n_eng, C, raw_bytes;
+    int spacing;
+    long n_frames;
+    const void *src; long src_ch_stride;           // in reals
+    int realsize;
+    int L;                         // block length: sample 0 of every block is NaN-checked
+    double max;                    // bfoverflow_t.max
+    DevOverflow *overflow;         // [n_eng*C]
+    int *bad_block;                // atomicMin of the first block with a non-finite sample 0
+    int block_base;                // index of the chunk's first block within the run
+};
+void launch_stage_out(const StageOutArgs &a, hipStream_t s);
+
+// a6 + a7 (and a16 with zero_first_half): real FFT of the N-sample window
+// starting at src + gc*src_ch_stride + t*L, written in the grouped layout to
+// dst + gc*dst_ch_stride + ((base_slot + t) % ring) * N.
+struct FwdArgs {
+    const void *src; long src_ch_stride;
+    void *dst; long dst_ch_stride;
+    int ring, base_slot;
+    int n_t, n_ch;
+    double load_scale, out_scale;
+    int zero_first_half;
+};
+void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s);
+
+// a8/a9/a10: Y[gc][t] = sum_{i < nblk[gc]} X[gc][slot(t - i)] * H[gc][i].
+struct MacArgs {
+    const void *x; long x_ch_stride; int ring, base_slot;
+    const void *h; long h_ch_stride;               // [gc][B][N]
+    const int *nblk;                               // device [n_ch]
+    void *y; long y_ch_stride;                     // [gc][n_t][N]
+    int n_t, n_ch, N, realsize;
+};
+void launch_mac(const MacArgs &a, hipStream_t s);
+
+// a11 + a12: inverse real FFT of Y[gc][t] (grouped layout, times in_scale),
+// first L samples to dst + gc*dst_ch_stride + t*L.
+struct InvArgs {
+    const void *src; long src_ch_stride;           // [gc][n_t][N]
+    void *dst; long dst_ch_stride;
+    int n_t, n_ch;
+    double in_scale;
+    int full_output;                               // 1: write all N samples at stride N (stage API)
+};
+void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
+
+// mixnscale with one buffer (a7 / a11) on half-complex data, for the stage API.
+void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_grouped, int realsize,
+                    hipStream_t s);
+
+// One convolve / convolve_add / convolve_inplace call of the stage API with the
+// reference's exact operation order (separate multiplies and adds).
+// mode 0: d = b*c, mode 1: d += b*c.  d may alias b (in-place form).
+void launch_cmul_stage(const void *b, const void *c, void *d, int n_fft, int mode, int realsize,
+                       hipStream_t s);
+
+}  // namespace bfir

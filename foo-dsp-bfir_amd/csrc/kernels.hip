@@ -1,0 +1,534 @@
+// kernels.hip -- hand-written gfx950 kernels of the partitioned-FIR hot path.
+//
+// One kernel per stage of brutefir::run (brutefir/brutefir.cpp:244-343), each
+// launched once over a whole chunk of blocks x channels:
+//   k_stage_in   a5   convolver_raw2cbuf            fftw_convolver.cpp:156-185
+//   k_fwd        a6+a7 time2freq + mixnscale INPUT  :187-212, :883-907 / :1583-1607
+//                a16  coeffs2cbuf (zero_first_half) :474-537
+//   k_mac        a8-a10 convolve / convolve_add / convolve_inplace
+//                                                   :1429-1525 / :2125-2220
+//   k_inv        a11+a12 mixnscale OUTPUT + freq2time :1163-1186, :350-375
+//   k_stage_out  a13  convolver_cbuf2raw            :405-466, real2raw.cpp:321-420
+// All spectra in HBM use the reference's grouped layout (4 real parts, then the
+// 4 imaginary parts of the same bins; Nyquist in slot 4), so one group is two
+// 16-byte vectors and every stage-level buffer is bit-compatible with a
+// reference cbuf.
+#include "kernels.h"
+
+#include <cmath>
+#include <vector>
+
+#include "fft_lds.h"
+
+namespace bfir {
+
+#define BFIR_FOR_LOG2M(F) \
+    F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14)
+
+// ---------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------
+template <int LOG2M> static void fill_tw(std::vector<long double> &tw)
+{
+    using F = LdsFft<float, LOG2M, -1>;
+    tw.assign(2 * (size_t)(F::twsize() > 0 ? F::twsize() : 1), 0.0L);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int s = 1; s < F::NP; s++) {
+        const int R = F::radix(s), p = F::pprod(s);
+        for (int r = 1; r < R; r++)
+            for (int k = 0; k < p; k++) {
+                long double ang = -two_pi * (long double)(r * k) / (long double)(p * R);
+                size_t o = (size_t)F::twoff(s) + (size_t)(r - 1) * p + k;
+                tw[2 * o] = cosl(ang);
+                tw[2 * o + 1] = sinl(ang);
+            }
+    }
+}
+
+template <typename T> static void *upload(const std::vector<long double> &v)
+{
+    std::vector<T> h(v.size());
+    for (size_t i = 0; i < v.size(); i++) h[i] = (T)v[i];
+    void *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    return d;
+}
+
+int fft_threads(int log2m)
+{
+    switch (log2m) {
+#define F(lg) case lg: return FftCfg<lg>::NT;
+        BFIR_FOR_LOG2M(F)
+#undef F
+    }
+    return 0;
+}
+
+int fft_plan_create(FftPlan *plan, int filter_length, int realsize)
+{
+    int lg = 0;
+    while ((1 << lg) < filter_length) lg++;
+    if ((1 << lg) != filter_length || lg < BFIR_MIN_LOG2M || lg > BFIR_MAX_LOG2M) return -1;
+    if (realsize != 4 && realsize != 8) return -1;
+    // one transform's LDS buffer must fit: M complex values
+    if ((size_t)filter_length * 2 * (size_t)realsize > 160 * 1024) return -1;
+    std::vector<long double> tw, ws;
+    switch (lg) {
+#define F(lgv) case lgv: fill_tw<lgv>(tw); break;
+        BFIR_FOR_LOG2M(F)
+#undef F
+    }
+    const int M = filter_length, N = 2 * M;
+    ws.resize(2 * (size_t)M);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int k = 0; k < M; k++) {
+        long double ang = -two_pi * (long double)k / (long double)N;
+        ws[2 * k] = cosl(ang);
+        ws[2 * k + 1] = sinl(ang);
+    }
+    plan->log2m = lg;
+    plan->realsize = realsize;
+    plan->tw = realsize == 4 ? upload<float>(tw) : upload<double>(tw);
+    plan->ws = realsize == 4 ? upload<float>(ws) : upload<double>(ws);
+    if (!plan->tw || !plan->ws) { fft_plan_destroy(plan); return -2; }
+    return 0;
+}
+
+void fft_plan_destroy(FftPlan *plan)
+{
+    if (plan->tw) (void)hipFree(plan->tw);
+    if (plan->ws) (void)hipFree(plan->ws);
+    plan->tw = plan->ws = nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// a6 + a7: forward real FFT into the grouped layout
+// ---------------------------------------------------------------------------
+template <typename T, int LOG2M>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
+                                                           const typename Vec2<T>::type *__restrict__ tw,
+                                                           const typename Vec2<T>::type *__restrict__ ws)
+{
+    using F = LdsFft<T, LOG2M, -1>;
+    using V2 = typename Vec2<T>::type;
+    using V4 = typename Vec4<T>::type;
+    constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
+    __shared__ __attribute__((aligned(16))) V2 lds[M];
+
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
+    const T *__restrict__ src = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * M;
+    T *__restrict__ dst =
+        (T *)a.dst + (long)gc * a.dst_ch_stride + (long)((a.base_slot + t) % a.ring) * N;
+
+    // z[m] = x[2m] + i x[2m+1] over the window [previous block | this block]
+    T re[P], im[P];
+    const T ls = (T)a.load_scale;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        const int m = F::in_index(tid, e);
+        if (a.zero_first_half && m < M / 2) {
+            re[e] = (T)0; im[e] = (T)0;
+        } else {
+            V2 v = *(const V2 *)(src + 2 * m);
+            re[e] = v.x * ls; im[e] = v.y * ls;
+        }
+    }
+
+    F::run(re, im, lds, tw, tid);
+
+    // Z in natural order to LDS so every thread can fetch Z[M-k]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        V2 v; v.x = re[e]; v.y = im[e];
+        lds[F::phys(F::out_index(tid, e))] = v;
+    }
+    __syncthreads();
+    // X_k = E_k + W^k O_k,  E = (Z_k + conj Z_{M-k})/2,  O = -i (Z_k - conj Z_{M-k})/2
+    const T os = (T)a.out_scale;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        const int k = F::out_index(tid, e);
+        V2 pz = lds[F::phys((M - k) & (M - 1))];
+        V2 w = ws[k];
+        T er = (T)0.5 * (re[e] + pz.x), ei = (T)0.5 * (im[e] - pz.y);
+        T orr = (T)0.5 * (im[e] + pz.y), oi = (T)-0.5 * (re[e] - pz.x);
+        T tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+        T xr = er + tr, xi = ei + ti;
+        if (k == 0) xi = re[e] - im[e];  // slot 4 carries Re X_{N/2}
+        re[e] = xr * os; im[e] = xi * os;
+    }
+    __syncthreads();
+    T *ldsr = (T *)lds;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        const int k = F::out_index(tid, e);
+        ldsr[8 * (k >> 2) + (k & 3)] = re[e];
+        ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+        const int idx = tid + j * NT;
+        ((V4 *)dst)[idx] = ((const V4 *)ldsr)[idx];
+    }
+}
+
+template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, const FwdArgs &a, int items, hipStream_t s)
+{
+    using V2 = typename Vec2<T>::type;
+    // a transform whose LDS buffer would not fit one CU is never instantiated
+    if constexpr (sizeof(T) * 2 * (size_t(1) << LOG2M) <= 160 * 1024)
+        hipLaunchKernelGGL((k_fwd<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+}
+
+void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
+{
+    const int items = a.n_t * a.n_ch;
+    if (items <= 0) return;
+    switch (plan.log2m) {
+#define F(lg)                                                              \
+    case lg:                                                               \
+        if (plan.realsize == 4) launch_fwd_t<float, lg>(plan, a, items, s); \
+        else launch_fwd_t<double, lg>(plan, a, items, s);                  \
+        break;
+        BFIR_FOR_LOG2M(F)
+#undef F
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a11 + a12: inverse real FFT from the grouped layout, valid half only
+// ---------------------------------------------------------------------------
+template <typename T, int LOG2M>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
+                                                           const typename Vec2<T>::type *__restrict__ tw,
+                                                           const typename Vec2<T>::type *__restrict__ ws)
+{
+    using F = LdsFft<T, LOG2M, +1>;
+    using V2 = typename Vec2<T>::type;
+    using V4 = typename Vec4<T>::type;
+    constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
+    __shared__ __attribute__((aligned(16))) V2 lds[M];
+
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
+    const T *__restrict__ src = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * N;
+    T *__restrict__ dst =
+        (T *)a.dst + (long)gc * a.dst_ch_stride + (long)t * (a.full_output ? N : M);
+
+    T *ldsr = (T *)lds;
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+        const int idx = tid + j * NT;
+        ((V4 *)ldsr)[idx] = ((const V4 *)src)[idx];
+    }
+    __syncthreads();
+
+    // Z_k = (X_k + conj X_{M-k}) + i conj(W^k) (X_k - conj X_{M-k})
+    T re[P], im[P];
+    const T sc = (T)a.in_scale;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        const int k = F::in_index(tid, e);
+        const int q = (k == 0) ? 0 : M - k;
+        T xr = ldsr[8 * (k >> 2) + (k & 3)] * sc, xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
+        T yr = ldsr[8 * (q >> 2) + (q & 3)] * sc, yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+        if (k == 0) { yr = xi; xi = (T)0; yi = (T)0; }  // X_0 = (DC, 0), X_M = (Nyquist, 0)
+        V2 w = ws[k];
+        T ar = xr + yr, ai = xi - yi, br = xr - yr, bi = xi + yi;
+        T tr = br * w.x + bi * w.y, ti = bi * w.x - br * w.y;
+        re[e] = ar - ti; im[e] = ai + tr;
+    }
+
+    F::run(re, im, lds, tw, tid);
+
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+        const int m = F::out_index(tid, e);
+        if (a.full_output || m < M / 2) {
+            V2 v; v.x = re[e]; v.y = im[e];
+            *(V2 *)(dst + 2 * m) = v;
+        }
+    }
+}
+
+template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, const InvArgs &a, int items, hipStream_t s)
+{
+    using V2 = typename Vec2<T>::type;
+    // a transform whose LDS buffer would not fit one CU is never instantiated
+    if constexpr (sizeof(T) * 2 * (size_t(1) << LOG2M) <= 160 * 1024)
+        hipLaunchKernelGGL((k_inv<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+}
+
+void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s)
+{
+    const int items = a.n_t * a.n_ch;
+    if (items <= 0) return;
+    switch (plan.log2m) {
+#define F(lg)                                                              \
+    case lg:                                                               \
+        if (plan.realsize == 4) launch_inv_t<float, lg>(plan, a, items, s); \
+        else launch_inv_t<double, lg>(plan, a, items, s);                  \
+        break;
+        BFIR_FOR_LOG2M(F)
+#undef F
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a8-a10: streaming complex multiply-accumulate over the partitions
+// ---------------------------------------------------------------------------
+// One thread owns one group (4 bins: V4 of real parts + V4 of imaginary parts)
+// of one channel for TT consecutive output blocks.  Walking the partitions
+// i = 0..nb-1 in the reference's order, it streams H_i once per tile and keeps
+// a sliding window of TT delay-line spectra in registers, so a spectrum is
+// fetched once per tile instead of once per output block.
+template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, const V4 &xr, const V4 &xi,
+                                                             const V4 &hr, const V4 &hi)
+{
+    ar.x += xr.x * hr.x; ar.x -= xi.x * hi.x; ai.x += xr.x * hi.x; ai.x += xi.x * hr.x;
+    ar.y += xr.y * hr.y; ar.y -= xi.y * hi.y; ai.y += xr.y * hi.y; ai.y += xi.y * hr.y;
+    ar.z += xr.z * hr.z; ar.z -= xi.z * hi.z; ai.z += xr.z * hi.z; ai.z += xi.z * hr.z;
+    ar.w += xr.w * hr.w; ar.w -= xi.w * hi.w; ai.w += xr.w * hi.w; ai.w += xi.w * hr.w;
+}
+
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
+{
+    using V4 = typename Vec4<T>::type;
+    // XCD-aware, bijective block -> work remap: each XCD (blocks b, b+8, ...)
+    // gets one contiguous range of work items, ordered (channel, bin tile)
+    // major / time tile minor, so its L2 holds a slice of H for the whole
+    // launch while consecutive time tiles re-use each other's spectra.
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTT, tt = w - s * nTT;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int g = bt * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int t0 = tt * TT;
+    const long slot4 = a.N / 4;  // V4 elements per spectrum
+    const V4 *__restrict__ X = (const V4 *)((const T *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
+    const V4 *__restrict__ H = (const V4 *)((const T *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+
+    V4 accr[TT], acci[TT], wr[TT], wi[TT];
+    T dc[TT], ny[TT];
+    int sl = (a.base_slot + t0) % ring;  // delay-line slot of block t0
+#pragma unroll
+    for (int j = 0; j < TT; j++) {
+        accr[j] = V4{0, 0, 0, 0}; acci[j] = V4{0, 0, 0, 0};
+        dc[j] = (T)0; ny[j] = (T)0;
+        int sj = sl + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
+    }
+    for (int i0 = 0; i0 < nb; i0 += TT) {
+#pragma unroll
+        for (int ii = 0; ii < TT; ii++) {
+            const int i = i0 + ii;
+            if (i < nb) {
+                const V4 hr = H[i * slot4], hi = H[i * slot4 + 1];
+#pragma unroll
+                for (int j = 0; j < TT; j++) {
+                    constexpr int TTc = TT;
+                    const int idx = (j - ii + TTc) % TTc;  // window slot holding X[t0 + j - i]
+                    cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                    // DC and Nyquist share group 0 as two independent reals
+                    dc[j] += wr[idx].x * hr.x;
+                    ny[j] += wi[idx].x * hi.x;
+                }
+                if (i + 1 < nb) {  // X[t0 - i - 1] replaces the entry nobody needs any more
+                    sl -= 1; if (sl < 0) sl += ring;
+                    wr[TT - 1 - ii] = X[sl * slot4]; wi[TT - 1 - ii] = X[sl * slot4 + 1];
+                }
+            }
+        }
+    }
+    T *__restrict__ Y = (T *)a.y + (long)gc * a.y_ch_stride;
+#pragma unroll
+    for (int j = 0; j < TT; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) {
+            if (g == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            V4 *yo = (V4 *)(Y + (long)t * a.N) + 2 * g;
+            yo[0] = accr[j]; yo[1] = acci[j];
+        }
+    }
+}
+
+template <typename T, int TT> static void launch_mac_t(const MacArgs &a, hipStream_t s)
+{
+    const int G = a.N / 8;
+    const int threads = G < 256 ? G : 256;
+    const int nbt = (G + threads - 1) / threads;
+    const int nTT = (a.n_t + TT - 1) / TT;
+    const int W = nTT * nbt * a.n_ch;
+    hipLaunchKernelGGL((k_mac<T, TT>), dim3(W), dim3(threads), 0, s, a, nbt, nTT, G);
+}
+
+void launch_mac(const MacArgs &a, hipStream_t s)
+{
+    if (a.n_t <= 0 || a.n_ch <= 0) return;
+    if (a.realsize == 4) {
+        if (a.n_t >= 8) launch_mac_t<float, 8>(a, s);
+        else if (a.n_t >= 4) launch_mac_t<float, 4>(a, s);
+        else if (a.n_t >= 2) launch_mac_t<float, 2>(a, s);
+        else launch_mac_t<float, 1>(a, s);
+    } else {
+        if (a.n_t >= 4) launch_mac_t<double, 4>(a, s);
+        else if (a.n_t >= 2) launch_mac_t<double, 2>(a, s);
+        else launch_mac_t<double, 1>(a, s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a5 / a13: staging between interleaved raw frames and planar time buffers
+// ---------------------------------------------------------------------------
+template <typename TR, typename T> __global__ __launch_bounds__(256) void k_stage_in(StageInArgs a)
+{
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (f >= a.n_frames) return;
+    const TR *__restrict__ raw =
+        (const TR *)((const char *)a.raw + (long)e * a.eng_stride_bytes) + (a.frame_off + f) * a.spacing;
+    T *__restrict__ dst = (T *)a.dst + (long)e * a.C * a.dst_ch_stride + a.dst_off + f;
+    for (int c = 0; c < a.C; c++) dst[(long)c * a.dst_ch_stride] = (T)raw[c];
+}
+
+void launch_stage_in(const StageInArgs &a, hipStream_t s)
+{
+    if (a.n_frames <= 0) return;
+    dim3 grid((unsigned)((a.n_frames + 255) / 256), a.n_eng), block(256);
+    if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_in<float, float>), grid, block, 0, s, a);
+    else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_in<float, double>), grid, block, 0, s, a);
+    else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_in<double, float>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_stage_in<double, double>), grid, block, 0, s, a);
+}
+
+__device__ __forceinline__ unsigned long long abs_bits(float v) { return (unsigned long long)__float_as_uint(fabsf(v)); }
+__device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+
+template <typename T, typename TR> __global__ __launch_bounds__(256) void k_stage_out(StageOutArgs a)
+{
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    const bool active = f < a.n_frames;
+    const T rmax = (T)a.max, rmin = (T)(-a.max);
+    TR *__restrict__ raw =
+        (TR *)((char *)a.raw + (long)e * a.eng_stride_bytes) + (a.frame_off + (active ? f : 0)) * a.spacing;
+    const T *__restrict__ src = (const T *)a.src + (long)e * a.C * a.src_ch_stride + (active ? f : 0);
+    const bool first_of_block = active && (f % a.L == 0);
+    for (int c = 0; c < a.C; c++) {
+        T v = active ? src[(long)c * a.src_ch_stride] : (T)0;
+        if (active) raw[c] = (TR)v;
+        // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+        const bool over = (v < (T)0) ? (v < rmin) : (v > rmax);
+        unsigned long long bits = (v == v) ? abs_bits(v) : 0ull;
+        const unsigned long long m = __ballot(over);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long other = __shfl_xor(bits, o);
+            bits = other > bits ? other : bits;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            DevOverflow *of = a.overflow + (e * a.C + c);
+            if (m) atomicAdd(&of->n_overflows, (unsigned int)__popcll(m));
+            if (bits) atomicMax(&of->largest_bits, bits);
+        }
+        // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+        if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+    }
+}
+
+void launch_stage_out(const StageOutArgs &a, hipStream_t s)
+{
+    if (a.n_frames <= 0) return;
+    dim3 grid((unsigned)((a.n_frames + 255) / 256), a.n_eng), block(256);
+    if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, float>), grid, block, 0, s, a);
+    else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_out<double, float>), grid, block, 0, s, a);
+    else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, double>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_stage_out<double, double>), grid, block, 0, s, a);
+}
+
+// ---------------------------------------------------------------------------
+// mixnscale with one buffer on half-complex data (stage API only)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_reorder(const T *__restrict__ in, T *__restrict__ out, int n_fft, T sc, int to_grouped)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = n_fft >> 1;
+    if (k >= half) return;
+    const int gr = 8 * (k >> 2) + (k & 3);
+    if (to_grouped) {  // brutefir/fftw_convolver.cpp:883-907
+        out[gr] = in[k] * sc;
+        out[gr + 4] = (k == 0 ? in[half] : in[n_fft - k]) * sc;
+    } else {           // :1163-1186
+        out[k] = in[gr] * sc;
+        if (k == 0) out[half] = in[4] * sc;
+        else out[n_fft - k] = in[gr + 4] * sc;
+    }
+}
+
+void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_grouped, int realsize,
+                    hipStream_t s)
+{
+    const int half = n_fft / 2, threads = 256, blocks = (half + threads - 1) / threads;
+    if (realsize == 4)
+        hipLaunchKernelGGL(k_reorder<float>, dim3(blocks), dim3(threads), 0, s, (const float *)in,
+                           (float *)out, n_fft, (float)scale, to_grouped);
+    else
+        hipLaunchKernelGGL(k_reorder<double>, dim3(blocks), dim3(threads), 0, s, (const double *)in,
+                           (double *)out, n_fft, scale, to_grouped);
+}
+
+// ---------------------------------------------------------------------------
+// stage API: one complex multiply(-add) pass in the reference's operation order
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+template <typename T>
+__global__ void k_cmul_stage(const T *b, const T *c, T *d, int n_fft, int mode)
+{
+    // one thread per bin; brutefir/fftw_convolver.cpp:1464-1525 (float), :2160-2220 (double)
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (n_fft >> 1)) return;
+    const int r = 8 * (k >> 2) + (k & 3), i = r + 4;
+    const T br = b[r], bi = b[i], cr = c[r], ci = c[i];
+    T pr, pi;
+    if (k == 0) {  // DC and Nyquist: two independent real products
+        pr = mul_rn(br, cr);
+        pi = mul_rn(bi, ci);
+    } else {
+        pr = add_rn(mul_rn(br, cr), -mul_rn(bi, ci));
+        pi = add_rn(mul_rn(br, ci), mul_rn(bi, cr));
+    }
+    if (mode == 1) { pr = add_rn(d[r], pr); pi = add_rn(d[i], pi); }
+    d[r] = pr; d[i] = pi;
+}
+
+void launch_cmul_stage(const void *b, const void *c, void *d, int n_fft, int mode, int realsize,
+                       hipStream_t s)
+{
+    const int half = n_fft / 2, threads = 256, blocks = (half + threads - 1) / threads;
+    if (realsize == 4)
+        hipLaunchKernelGGL(k_cmul_stage<float>, dim3(blocks), dim3(threads), 0, s, (const float *)b,
+                           (const float *)c, (float *)d, n_fft, mode);
+    else
+        hipLaunchKernelGGL(k_cmul_stage<double>, dim3(blocks), dim3(threads), 0, s, (const double *)b,
+                           (const double *)c, (double *)d, n_fft, mode);
+}
+
+}  // namespace bfir

@@ -1,0 +1,232 @@
+"""Parity of the fused HIP engine (bfir_engine_* through the C ABI) with the CPU oracle.
+
+Tolerance: max|y - y_oracle| / max|y_oracle| <= 1e-5 (realsize 4) / 1e-12 (realsize 8),
+the figures BASELINE.json's north_star states."""
+import numpy as np
+import pytest
+
+from conftest import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+# (realsize, L, B, C, taps, n_blocks, chunk)
+CONFIGS = [
+    (4, 4096, 2, 2, 8192, 7, 64),       # BASELINE configs[0] shape
+    (4, 8192, 8, 2, 65536, 19, 8),      # configs[1] shape, first 2B+3 blocks
+    (4, 4096, 32, 8, 131072, 67, 16),   # configs[2] headline shape, 2B+3 blocks
+    (8, 4096, 64, 2, 262144, 131, 32),  # configs[4] fp64, 2B+3 blocks
+    (4, 1024, 1, 2, 1000, 5, 2),        # single partition (convolve_inplace branch), ragged tail
+    (8, 1024, 4, 3, 4000, 11, 3),       # plug-in default L, odd channel count, ragged tail
+    (4, 256, 5, 8, 1100, 23, 7),        # chunk not dividing the run, B not a power of two
+    (4, 16, 3, 1, 40, 9, 4),            # smallest supported partition
+    (8, 64, 2, 8, 128, 6, 1),           # block-at-a-time
+    (4, 16384, 2, 1, 20000, 3, 2),      # largest fp32 partition
+    (8, 8192, 2, 1, 9000, 3, 2),        # largest fp64 partition
+]
+
+
+def _make(orc, s, C, taps, frames, seed):
+    rng = np.random.default_rng(seed)
+    dt = orc.real_dtype(s)
+    return orc.synth_ir(rng, C, taps, dt), orc.synth_audio(rng, frames, C, dt)
+
+
+@pytest.mark.parametrize("s,L,B,C,taps,nb,chunk", CONFIGS)
+def test_run_matches_oracle(orc, bfir, s, L, B, C, taps, nb, chunk):
+    h, x = _make(orc, s, C, taps, nb * L, seed=L + B + C)
+    ref = orc.Engine(L, B, s, C)
+    assert ref.set_coeff(h) == 0
+    rc_ref, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, s, C)
+    eng.set_chunk(chunk)
+    assert not eng.is_initialized()
+    assert eng.set_coeff(h) == 0
+    assert eng.is_initialized()
+    rc, y = eng.run(x)
+    assert rc == rc_ref == 0
+    assert rel_err(y, y_ref) <= TOL[s]
+    for c in range(C):
+        o, r = eng.overflow(c), ref.overflow(c)
+        assert o.max == r.max == 1.0
+        assert abs(o.largest - r.largest) <= TOL[s] * max(r.largest, 1e-30)
+        assert o.n_overflows == r.n_overflows == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("s", [4, 8])
+def test_partition_spectra_match_oracle(orc, bfir, s):
+    L, B, C, taps = 512, 5, 2, 2100   # ragged tail: block 4 holds 52 taps
+    h, _ = _make(orc, s, C, taps, L, seed=11)
+    ref = orc.Engine(L, B, s, C)
+    ref.set_coeff(h, scale=0.5)
+    eng = bfir.Brutefir(L, B, s, C)
+    assert eng.set_coeff(h, scale=0.5) == 0
+    for c in range(C):
+        for b in range(B):
+            assert rel_err(eng.coeff_block(c, b), ref.coeff_block(c, b)) <= TOL[s]
+
+
+def test_chunking_is_bitwise_invariant(orc, bfir):
+    s, L, B, C, nb = 4, 1024, 6, 4, 29
+    h, x = _make(orc, s, C, B * L - 17, nb * L, seed=5)
+    outs = []
+    for chunk in (1, 2, 5, 8, 64):
+        eng = bfir.Brutefir(L, B, s, C)
+        eng.set_chunk(chunk)
+        assert eng.set_coeff(h) == 0
+        rc, y = eng.run(x)
+        assert rc == 0
+        outs.append(y)
+        eng.close()
+    for y in outs[1:]:
+        assert np.array_equal(y, outs[0])
+
+
+def test_streaming_calls_equal_one_call(orc, bfir):
+    """run() block by block (the plug-in's pattern, foo_dsp_bfir.cpp:311-349) == one batched call."""
+    s, L, B, C, nb = 8, 256, 4, 2, 13
+    h, x = _make(orc, s, C, 1000, nb * L, seed=6)
+    a = bfir.Brutefir(L, B, s, C); a.set_coeff(h)
+    _, y_all = a.run(x)
+    b = bfir.Brutefir(L, B, s, C); b.set_coeff(h)
+    parts = [b.run(x[t * L:(t + 1) * L])[1] for t in range(nb)]
+    assert np.array_equal(np.concatenate(parts), y_all)
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt,s", [(8, 8, 8), (10, 10, 4), (8, 10, 4), (10, 8, 8)])
+def test_mixed_sample_widths(orc, bfir, in_fmt, out_fmt, s):
+    """float32 I/O around fp64 arithmetic is the plug-in's own configuration
+    (foo_dsp_bfir/common.h:17, foo_dsp_bfir.cpp:283-284)."""
+    L, B, C, nb = 512, 3, 2, 8
+    rng = np.random.default_rng(3)
+    h = orc.synth_ir(rng, C, 1400, orc.real_dtype(s))
+    x = orc.synth_audio(rng, nb * L, C, orc.fmt_dtype(in_fmt))
+    ref = orc.Engine(L, B, s, C, in_fmt, out_fmt); ref.set_coeff(h)
+    _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, s, C, in_fmt, out_fmt); eng.set_coeff(h)
+    rc, y = eng.run(x)
+    assert rc == 0 and y.dtype == y_ref.dtype
+    tol = 1e-5 if (s == 4 or out_fmt == 8) else 1e-12
+    assert rel_err(y, y_ref) <= tol
+
+
+def test_overflow_counters(orc, bfir):
+    s, L, B, C, nb = 4, 512, 2, 3, 10
+    rng = np.random.default_rng(9)
+    h = [np.r_[np.float32(g), np.zeros(700, np.float32)] for g in (0.5, 1.5, 3.0)]  # pure gains
+    x = orc.synth_audio(rng, nb * L, C, np.float32)
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, s, C); eng.set_coeff(h); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, y_ref) <= TOL[s]
+    # exact counts are only comparable when no sample sits on the threshold
+    margin = np.abs(np.abs(y_ref.astype(np.float64)) - 1.0).min()
+    assert margin > 1e-5
+    for c in range(C):
+        o, r = eng.overflow(c), ref.overflow(c)
+        assert o.n_overflows == r.n_overflows
+        assert abs(o.largest - r.largest) <= 1e-5 * r.largest
+    assert eng.overflow(0).n_overflows == 0 and eng.overflow(2).n_overflows > 0
+    report = eng.check_overflows()
+    assert [n for n, _, _ in report] == [0, 1, 2] and report[2][2] > 0.0
+    eng.reset()
+    assert eng.overflow(2).n_overflows == 0 and eng.overflow(2).largest == 0.0
+
+
+def test_reset_keeps_time_history_like_reference(orc, bfir):
+    """brutefir::reset clears counters only (brutefir.cpp:346-367): the first block after it
+    still sees the stale half of input_timecbuf[n][0]."""
+    s, L, B, C = 8, 128, 3, 2
+    h, x = _make(orc, s, C, 300, 9 * L, seed=21)
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h)
+    eng = bfir.Brutefir(L, B, s, C); eng.set_coeff(h)
+    for nblk in (3, 2, 1, 1):   # odd and even call counts before each reset
+        seg = x[:nblk * L]
+        _, yr = ref.run(seg); rc, y = eng.run(seg)
+        assert rc == 0 and rel_err(y, yr) <= TOL[s]
+        ref.reset(); eng.reset()
+        x = x[nblk * L:]
+    _, yr = ref.run(x); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, yr) <= TOL[s]
+
+
+def test_nonfinite_input_returns_minus_one(orc, bfir):
+    s, L, B, C = 4, 256, 2, 2
+    h, x = _make(orc, s, C, 400, 4 * L, seed=2)
+    x[L + 5, 1] = np.nan
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h)
+    eng = bfir.Brutefir(L, B, s, C); eng.set_coeff(h)
+    assert ref.run(x)[0] == -1
+    assert eng.run(x)[0] == -1
+    # the verdict is consumed; a clean engine state needs B clean blocks, as in the reference
+
+
+def test_nonfinite_coefficient_returns_minus_two(orc, bfir):
+    eng = bfir.Brutefir(256, 2, 4, 2)
+    h = [np.ones(300, np.float32), np.ones(300, np.float32)]
+    h[1][7] = np.inf
+    assert eng.set_coeff(h) == -2
+    assert not eng.is_initialized()
+    assert eng.run(np.zeros((256, 2), np.float32))[0] == bfir.ERR_STATE
+
+
+def test_fewer_coefficient_blocks_than_filter_blocks(orc, bfir):
+    """coeffs[n].n_blocks < n_blocks (brutefir.cpp:292)."""
+    s, L, B, C, nb = 4, 256, 6, 2, 15
+    h, x = _make(orc, s, C, 3 * L, nb * L, seed=8)
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h, coeff_blocks=3)
+    eng = bfir.Brutefir(L, B, s, C); assert eng.set_coeff(h, coeff_blocks=3) == 0
+    _, yr = ref.run(x); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, yr) <= TOL[s]
+
+
+def test_dirac_is_identity(bfir):
+    """coeff::load_dirac_coeff's impulse (brutefir/coeff.cpp) passes audio through unchanged."""
+    L, B, C, nb = 1024, 4, 2, 9
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (nb * L, C)).astype(np.float32)
+    d = np.zeros(B * L, np.float32); d[0] = 1.0
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_coeff([d, d])
+    rc, y = eng.run(x)
+    assert rc == 0 and np.abs(y - x).max() <= 1e-5
+
+
+def test_batch_of_engines_matches_single_engines(orc, bfir):
+    """BASELINE configs[3] shape at reduced size: independent stereo streams sharing launches."""
+    s, L, B, C, nb, E = 4, 512, 4, 2, 11, 5
+    rng = np.random.default_rng(17)
+    hs = [orc.synth_ir(rng, C, B * L, np.float32) for _ in range(E)]
+    xs = np.stack([orc.synth_audio(rng, nb * L, C, np.float32) for _ in range(E)])
+    batch = bfir.Brutefir(L, B, s, C, n_engines=E)
+    batch.set_chunk(4)
+    for e in range(E):
+        assert batch.set_coeff(hs[e], engine_index=e) == 0
+    rc, y = batch.run(xs)
+    assert rc == 0
+    for e in range(E):
+        ref = orc.Engine(L, B, s, C); ref.set_coeff(hs[e])
+        assert rel_err(y[e], ref.run(xs[e])[1]) <= TOL[s]
+        one = bfir.Brutefir(L, B, s, C); one.set_chunk(4); one.set_coeff(hs[e])
+        assert np.array_equal(one.run(xs[e])[1], y[e])
+
+
+def test_run_device_on_torch_stream(orc, bfir):
+    import torch
+    s, L, B, C, nb = 4, 2048, 8, 8, 40
+    h, x = _make(orc, s, C, B * L, nb * L, seed=4)
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, s, C); eng.set_chunk(16); eng.set_coeff(h)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    st = torch.cuda.current_stream().cuda_stream
+    eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, stream=st)
+    assert eng.sync() == 0
+    assert rel_err(d_out.cpu().numpy(), y_ref) <= TOL[s]
+
+
+def test_create_rejects_bad_arguments(bfir):
+    for args in [(1000, 2, 4, 2), (1024, 2, 6, 2), (1024, 2, 4, 9), (1024, 0, 4, 2), (8, 2, 4, 2),
+                 (16384, 2, 8, 1)]:
+        with pytest.raises(bfir.BfirError):
+            bfir.Brutefir(*args)
+    with pytest.raises(bfir.BfirError):
+        bfir.Brutefir(1024, 2, 4, 2, in_format=2)   # S16_LE: not on the float path yet

@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the partitioned-FIR hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the headline): 8 channels, 131072-tap IR,
+4096-sample partitions (N = 8192, B = 32), fp32, synthetic uniform noise.
+One STEP = one bfir_engine_run_device call over `--blocks` consecutive blocks
+of input that is already resident in HBM.  Metric: output channel-samples/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank runs its
+own independent 8-channel engine (weak scaling, no data-path collective).
+
+The JSON line also carries
+  roofline     algorithmic HBM bytes of the dominant kernel / its mean launch
+               time (HIP events on the launch stream) against 8 TB/s
+  cpu_baseline the CPU oracle (a port of the reference algorithm) timed on a
+               bounded sample of the same workload on this host, 1 thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (channels, taps, L, realsize)
+    "cfg3_8ch_131072tap_L4096_fp32": (8, 131072, 4096, 4),
+    "cfg2_2ch_65536tap_L8192_fp32": (2, 65536, 8192, 4),
+    "cfg5_2ch_262144tap_L4096_fp64": (2, 262144, 4096, 8),
+}
+
+
+def algorithmic_bytes_per_block(C, B, N, L, s):
+    """bytes one run() block must move, split by the kernel that moves them."""
+    return {
+        "k_stage_in": C * s * L,          # input block
+        "k_fwd": C * s * N,               # new delay-line slot
+        "k_mac": C * s * 2 * B * N,       # all partition spectra + all delay-line spectra
+        "k_inv": 0,
+        "k_stage_out": C * s * L,         # output block
+    }
+
+
+def cpu_baseline(O, C, taps, L, B, s, h, x, budget_s=12.0):
+    """Time the oracle (1 thread) on a bounded sample: B warm-up blocks, then blocks until ~budget."""
+    eng = O.Engine(L, B, s, C)
+    assert eng.set_coeff(h) == 0
+    nb_avail = x.shape[0] // L
+    warm = min(B, nb_avail)
+    eng.run(x[:warm * L])
+    # calibrate on a few blocks, then one timed run sized to the budget
+    t0 = time.perf_counter()
+    cal = min(8, nb_avail)
+    eng.run(x[:cal * L])
+    per_block = (time.perf_counter() - t0) / cal
+    n = int(max(cal, min(nb_avail, budget_s / max(per_block, 1e-9))))
+    t0 = time.perf_counter()
+    rc, _ = eng.run(x[:n * L])
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": n * L * C / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d blocks (%d channel-samples) after %d warm-up blocks, oracle/bfir_oracle.c, "
+                      "1 thread, %.1f s" % (n, n * L * C, warm, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per step")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "128")),
+                    help="blocks per kernel launch")
+    ap.add_argument("--workload", default="cfg3_8ch_131072tap_L4096_fp32", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import foo_dsp_bfir_amd as bfir   # raises if the HIP library is missing
+
+    C, taps, L, s = WORKLOADS[args.workload]
+    N, B = 2 * L, (taps + L - 1) // L
+    rdt = np.float32 if s == 4 else np.float64
+    tdt = torch.float32 if s == 4 else torch.float64
+    nb = args.blocks
+
+    # synthetic audio / IR of SURVEY.md 8(d); every rank has its own stream
+    rng = np.random.default_rng(3 + 1000 * rank)
+    n = np.arange(taps, dtype=np.float64)
+    h = []
+    for _ in range(C):
+        v = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n / taps)
+        h.append((v / np.abs(v).sum()).astype(rdt))
+    x_host = rng.uniform(-1.0, 1.0, (nb * L, C)).astype(rdt)
+
+    eng = bfir.Brutefir(L, B, s, C, device=local)
+    eng.set_chunk(args.chunk)
+    assert eng.set_coeff(h) == 0
+    d_in = torch.from_numpy(x_host).to(dev)
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, stream=stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    assert eng.sync() == 0
+    eng.set_profiling(not args.no_kernel_events)   # also zeroes the counters
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert eng.sync() == 0
+    prof = eng.profile()
+    eng.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = nb * L * C
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+
+    result = None
+    if rank == 0:
+        alg = algorithmic_bytes_per_block(C, B, N, L, s)
+        roofline = None
+        if not args.no_kernel_events and any(v[1] for v in prof.values()):
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, launches = prof[dom]
+            blocks_per_launch = args.steps * nb / launches
+            achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None,
+                        "algorithmic_bytes_per_launch": int(alg[dom] * blocks_per_launch),
+                        "avg_launch_ms": round(ms / launches, 5),
+                        "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)
+                                            for k, v in prof.items()}}
+        cpu = None
+        parity = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O   # checker + CPU baseline only
+            O.build()
+            cpu = cpu_baseline(O, C, taps, L, B, s, h, x_host)
+            # parity of this very workload: first blocks of a fresh GPU engine vs the oracle
+            k = min(nb, B + 3)
+            ref = O.Engine(L, B, s, C); ref.set_coeff(h)
+            _, y_ref = ref.run(x_host[:k * L])
+            chk = bfir.Brutefir(L, B, s, C, device=local); chk.set_coeff(h)
+            rc, y = chk.run(x_host[:k * L])
+            parity = float(np.abs(y.astype(np.float64) - y_ref).max() / np.abs(y_ref).max())
+            assert rc == 0 and parity <= (1e-5 if s == 4 else 1e-12), parity
+        result = {
+            "metric": "Msamples/s (output channel-samples), 8ch 131072-tap FIR @4096-sample partitions"
+                      if args.workload.startswith("cfg3") else "Msamples/s (output channel-samples)",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if s == 4 else "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "channels": C, "taps": taps, "partition": L,
+                       "fft_size": N, "partitions": B, "blocks_per_step": nb,
+                       "blocks_per_launch": args.chunk, "engines_per_gpu": 1,
+                       "io": "interleaved frames resident in HBM", "parallelism": "replica-per-gpu"},
+            "per_gpu_value": round(value / world, 1),
+            "pct_of_hbm_roofline_algorithmic": round(
+                100.0 * (value / world * 1e6) * (sum(alg.values()) / (L * C)) / (HBM_PEAK_GBS * 1e9), 2),
+            "roofline": roofline, "cpu_baseline": cpu, "parity_rel_err_vs_oracle": parity,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -291,13 +291,15 @@ void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s)
 // i = 0..nb-1 in the reference's order, it streams H_i once per tile and keeps
 // a sliding window of TT delay-line spectra in registers, so a spectrum is
 // fetched once per tile instead of once per output block.
+// Explicit fma() calls pin the rounding: every instantiation (any TT) produces
+// bit-identical sums, so results do not depend on how a run is cut into chunks.
 template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, const V4 &xr, const V4 &xi,
                                                              const V4 &hr, const V4 &hi)
 {
-    ar.x += xr.x * hr.x; ar.x -= xi.x * hi.x; ai.x += xr.x * hi.x; ai.x += xi.x * hr.x;
-    ar.y += xr.y * hr.y; ar.y -= xi.y * hi.y; ai.y += xr.y * hi.y; ai.y += xi.y * hr.y;
-    ar.z += xr.z * hr.z; ar.z -= xi.z * hi.z; ai.z += xr.z * hi.z; ai.z += xi.z * hr.z;
-    ar.w += xr.w * hr.w; ar.w -= xi.w * hi.w; ai.w += xr.w * hi.w; ai.w += xi.w * hr.w;
+    ar.x = fma(xr.x, hr.x, ar.x); ar.x = fma(-xi.x, hi.x, ar.x); ai.x = fma(xr.x, hi.x, ai.x); ai.x = fma(xi.x, hr.x, ai.x);
+    ar.y = fma(xr.y, hr.y, ar.y); ar.y = fma(-xi.y, hi.y, ar.y); ai.y = fma(xr.y, hi.y, ai.y); ai.y = fma(xi.y, hr.y, ai.y);
+    ar.z = fma(xr.z, hr.z, ar.z); ar.z = fma(-xi.z, hi.z, ar.z); ai.z = fma(xr.z, hi.z, ai.z); ai.z = fma(xi.z, hr.z, ai.z);
+    ar.w = fma(xr.w, hr.w, ar.w); ar.w = fma(-xi.w, hi.w, ar.w); ai.w = fma(xr.w, hi.w, ai.w); ai.w = fma(xi.w, hr.w, ai.w);
 }
 
 template <typename T, int TT>
@@ -320,6 +322,9 @@ __global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
     const V4 *__restrict__ H = (const V4 *)((const T *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
     const int nb = a.nblk[gc];
     const int ring = a.ring;
+    // DC and Nyquist share group 0 as two independent reals; only the wave
+    // that owns group 0 carries the two extra sums
+    const bool wave0 = (bt == 0) && (threadIdx.x < 64);
 
     V4 accr[TT], acci[TT], wr[TT], wi[TT];
     T dc[TT], ny[TT];
@@ -342,9 +347,10 @@ __global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
                     constexpr int TTc = TT;
                     const int idx = (j - ii + TTc) % TTc;  // window slot holding X[t0 + j - i]
                     cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
-                    // DC and Nyquist share group 0 as two independent reals
-                    dc[j] += wr[idx].x * hr.x;
-                    ny[j] += wi[idx].x * hi.x;
+                    if (wave0) {
+                        dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                        ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                    }
                 }
                 if (i + 1 < nb) {  // X[t0 - i - 1] replaces the entry nobody needs any more
                     sl -= 1; if (sl < 0) sl += ring;

@@ -83,6 +83,31 @@ def library_path():
     return _build.LIB
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the
+    same SONAME as /opt/rocm's).  If libbfir_hip.so is loaded first it binds the
+    system copy, a later `import torch` maps the bundled copy as a second
+    runtime, and that one finds no GPU.  Mapping torch's copy first (without
+    importing torch) makes both resolve to the same runtime, so device
+    pointers, streams and synchronisation are shared.  BFIR_HIP_RUNTIME=system
+    skips this (for processes that never import torch)."""
+    import sys
+    if os.environ.get("BFIR_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # no torch, or an unusual install: the system runtime is used
+
+
 def load():
     """dlopen libbfir_hip.so and attach the prototypes.  Raises if it is absent."""
     global _lib
@@ -93,6 +118,7 @@ def load():
         raise RuntimeError(
             "libbfir_hip.so is not built (%s); run __graft_entry__.build() -- "
             "there is no CPU fallback for the convolution engine" % path)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

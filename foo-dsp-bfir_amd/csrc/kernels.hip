@@ -22,6 +22,8 @@
 
 namespace bfir {
 
+constexpr int BFIR_MAXCH = 8;   // BF_MAXCHANNELS, brutefir/global.h:21
+
 #define BFIR_FOR_LOG2M(F) \
     F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14)
 
@@ -302,8 +304,8 @@ template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, con
     ar.w = fma(xr.w, hr.w, ar.w); ar.w = fma(-xi.w, hi.w, ar.w); ai.w = fma(xr.w, hi.w, ai.w); ai.w = fma(xi.w, hr.w, ai.w);
 }
 
-template <typename T, int TT>
-__global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
+template <typename T, int TT, int WPE>
+__global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, int G)
 {
     using V4 = typename Vec4<T>::type;
     // XCD-aware, bijective block -> work remap: each XCD (blocks b, b+8, ...)
@@ -336,12 +338,21 @@ __global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
         int sj = sl + j; if (sj >= ring) sj -= ring;
         wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
     }
+    V4 hr = H[0], hi = H[1];
+    // Partitions in the reference's order i = 0 .. nb-1, TT per trip so the
+    // rotating window keeps compile-time register names.  Every step first
+    // issues the loads of the NEXT step (partition i+1 and the one new
+    // delay-line spectrum X[t0-i-1]), then does its TT x 4 complex MACs, so a
+    // whole step of arithmetic covers the load latency.
     for (int i0 = 0; i0 < nb; i0 += TT) {
 #pragma unroll
         for (int ii = 0; ii < TT; ii++) {
             const int i = i0 + ii;
-            if (i < nb) {
-                const V4 hr = H[i * slot4], hi = H[i * slot4 + 1];
+            if (i < nb) {   // wave-uniform
+                const int in = (i + 1 < nb) ? i + 1 : i;
+                const V4 hrn = H[in * slot4], hin = H[in * slot4 + 1];
+                sl -= 1; if (sl < 0) sl += ring;
+                const V4 xrn = X[sl * slot4], xin = X[sl * slot4 + 1];
 #pragma unroll
                 for (int j = 0; j < TT; j++) {
                     constexpr int TTc = TT;
@@ -352,10 +363,8 @@ __global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
                         ny[j] = fma(wi[idx].x, hi.x, ny[j]);
                     }
                 }
-                if (i + 1 < nb) {  // X[t0 - i - 1] replaces the entry nobody needs any more
-                    sl -= 1; if (sl < 0) sl += ring;
-                    wr[TT - 1 - ii] = X[sl * slot4]; wi[TT - 1 - ii] = X[sl * slot4 + 1];
-                }
+                wr[TT - 1 - ii] = xrn; wi[TT - 1 - ii] = xin;  // X[t0-i-1] replaces the entry nobody needs any more
+                hr = hrn; hi = hin;
             }
         }
     }
@@ -371,49 +380,98 @@ __global__ __launch_bounds__(256) void k_mac(MacArgs a, int nbt, int nTT, int G)
     }
 }
 
-template <typename T, int TT> static void launch_mac_t(const MacArgs &a, hipStream_t s)
+template <typename T, int TT, int WPE> static void launch_mac_t(const MacArgs &a, hipStream_t s)
 {
     const int G = a.N / 8;
     const int threads = G < 256 ? G : 256;
     const int nbt = (G + threads - 1) / threads;
     const int nTT = (a.n_t + TT - 1) / TT;
     const int W = nTT * nbt * a.n_ch;
-    hipLaunchKernelGGL((k_mac<T, TT>), dim3(W), dim3(threads), 0, s, a, nbt, nTT, G);
+    hipLaunchKernelGGL((k_mac<T, TT, WPE>), dim3(W), dim3(threads), 0, s, a, nbt, nTT, G);
+}
+
+// BFIR_MAC_TT (tuning aid): cap the time tile of the MAC kernel.
+static int mac_tt_cap()
+{
+    static int cap = -1;
+    if (cap < 0) {
+        const char *e = getenv("BFIR_MAC_TT");
+        cap = e ? atoi(e) : 0;
+        if (cap <= 0) cap = 1 << 30;
+    }
+    return cap;
 }
 
 void launch_mac(const MacArgs &a, hipStream_t s)
 {
     if (a.n_t <= 0 || a.n_ch <= 0) return;
+    const int cap = mac_tt_cap();
+    const int tt = a.n_t < cap ? a.n_t : cap;
     if (a.realsize == 4) {
-        if (a.n_t >= 8) launch_mac_t<float, 8>(a, s);
-        else if (a.n_t >= 4) launch_mac_t<float, 4>(a, s);
-        else if (a.n_t >= 2) launch_mac_t<float, 2>(a, s);
-        else launch_mac_t<float, 1>(a, s);
+        if (tt >= 8) launch_mac_t<float, 8, 2>(a, s);
+        else if (tt >= 4) launch_mac_t<float, 4, 3>(a, s);
+        else if (tt >= 2) launch_mac_t<float, 2, 4>(a, s);
+        else launch_mac_t<float, 1, 4>(a, s);
     } else {
-        if (a.n_t >= 4) launch_mac_t<double, 4>(a, s);
-        else if (a.n_t >= 2) launch_mac_t<double, 2>(a, s);
-        else launch_mac_t<double, 1>(a, s);
+        if (tt >= 4) launch_mac_t<double, 4, 2>(a, s);
+        else if (tt >= 2) launch_mac_t<double, 2, 3>(a, s);
+        else launch_mac_t<double, 1, 4>(a, s);
     }
 }
 
 // ---------------------------------------------------------------------------
 // a5 / a13: staging between interleaved raw frames and planar time buffers
 // ---------------------------------------------------------------------------
-template <typename TR, typename T> __global__ __launch_bounds__(256) void k_stage_in(StageInArgs a)
+// Both directions move one tile of STAGE_TILE frames x C channels per step
+// through LDS, so the interleaved side is touched with contiguous (16-byte when
+// aligned) accesses and the planar side with lane-consecutive ones, whatever C
+// and the sample widths are.
+constexpr int STAGE_TILE = 256;
+
+template <typename W> __device__ __forceinline__ void tile_copy(W *dst, const W *src, int n, int tid)
 {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
-    if (f >= a.n_frames) return;
-    const TR *__restrict__ raw =
-        (const TR *)((const char *)a.raw + (long)e * a.eng_stride_bytes) + (a.frame_off + f) * a.spacing;
-    T *__restrict__ dst = (T *)a.dst + (long)e * a.C * a.dst_ch_stride + a.dst_off + f;
-    for (int c = 0; c < a.C; c++) dst[(long)c * a.dst_ch_stride] = (T)raw[c];
+    for (int i = tid; i < n; i += STAGE_TILE) dst[i] = src[i];
+}
+
+// contiguous global <-> LDS copy of `bytes` bytes (multiple of 4)
+__device__ __forceinline__ void tile_load(void *lds, const void *g, int bytes, int tid)
+{
+    if ((((size_t)g) & 15) == 0 && (bytes & 15) == 0) tile_copy((uint4 *)lds, (const uint4 *)g, bytes >> 4, tid);
+    else tile_copy((unsigned int *)lds, (const unsigned int *)g, bytes >> 2, tid);
+}
+__device__ __forceinline__ void tile_store(void *g, const void *lds, int bytes, int tid)
+{
+    if ((((size_t)g) & 15) == 0 && (bytes & 15) == 0) tile_copy((uint4 *)g, (const uint4 *)lds, bytes >> 4, tid);
+    else tile_copy((unsigned int *)g, (const unsigned int *)lds, bytes >> 2, tid);
+}
+
+template <typename TR, typename T> __global__ __launch_bounds__(STAGE_TILE) void k_stage_in(StageInArgs a)
+{
+    __shared__ __attribute__((aligned(16))) TR tile[STAGE_TILE * BFIR_MAXCH];
+    const int tid = threadIdx.x, e = blockIdx.y, C = a.C;
+    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
+    const TR *__restrict__ raw = (const TR *)((const char *)a.raw + (long)e * a.eng_stride_bytes) + a.frame_off * a.spacing;
+    T *__restrict__ dst = (T *)a.dst + (long)e * C * a.dst_ch_stride + a.dst_off;
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long f0 = tl * STAGE_TILE;
+        const int nf = (int)((a.n_frames - f0) < STAGE_TILE ? (a.n_frames - f0) : STAGE_TILE);
+        if (a.spacing == C) {
+            tile_load(tile, raw + f0 * C, nf * C * (int)sizeof(TR), tid);
+        } else {  // channels are a subset of a wider frame (stage API): strided gather
+            for (int i = tid; i < nf * C; i += STAGE_TILE) tile[i] = raw[(f0 + i / C) * a.spacing + i % C];
+        }
+        __syncthreads();
+        if (tid < nf)
+            for (int c = 0; c < C; c++) dst[(long)c * a.dst_ch_stride + f0 + tid] = (T)tile[tid * C + c];
+        __syncthreads();
+    }
 }
 
 void launch_stage_in(const StageInArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
-    dim3 grid((unsigned)((a.n_frames + 255) / 256), a.n_eng), block(256);
+    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
+    dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), a.n_eng), block(STAGE_TILE);
     if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_in<float, float>), grid, block, 0, s, a);
     else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_in<float, double>), grid, block, 0, s, a);
     else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_in<double, float>), grid, block, 0, s, a);
@@ -423,42 +481,80 @@ void launch_stage_in(const StageInArgs &a, hipStream_t s)
 __device__ __forceinline__ unsigned long long abs_bits(float v) { return (unsigned long long)__float_as_uint(fabsf(v)); }
 __device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
-template <typename T, typename TR> __global__ __launch_bounds__(256) void k_stage_out(StageOutArgs a)
+template <typename T, typename TR> __global__ __launch_bounds__(STAGE_TILE) void k_stage_out(StageOutArgs a)
 {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
-    const bool active = f < a.n_frames;
+    __shared__ __attribute__((aligned(16))) TR tile[STAGE_TILE * BFIR_MAXCH];
+    __shared__ unsigned long long red_max[STAGE_TILE / 64][BFIR_MAXCH];
+    __shared__ unsigned int red_cnt[STAGE_TILE / 64][BFIR_MAXCH];
+    const int tid = threadIdx.x, e = blockIdx.y, C = a.C;
+    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
     const T rmax = (T)a.max, rmin = (T)(-a.max);
-    TR *__restrict__ raw =
-        (TR *)((char *)a.raw + (long)e * a.eng_stride_bytes) + (a.frame_off + (active ? f : 0)) * a.spacing;
-    const T *__restrict__ src = (const T *)a.src + (long)e * a.C * a.src_ch_stride + (active ? f : 0);
-    const bool first_of_block = active && (f % a.L == 0);
-    for (int c = 0; c < a.C; c++) {
-        T v = active ? src[(long)c * a.src_ch_stride] : (T)0;
-        if (active) raw[c] = (TR)v;
-        // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
-        const bool over = (v < (T)0) ? (v < rmin) : (v > rmax);
-        unsigned long long bits = (v == v) ? abs_bits(v) : 0ull;
-        const unsigned long long m = __ballot(over);
+    TR *__restrict__ raw = (TR *)((char *)a.raw + (long)e * a.eng_stride_bytes) + a.frame_off * a.spacing;
+    const T *__restrict__ src = (const T *)a.src + (long)e * C * a.src_ch_stride;
+    unsigned long long mx[BFIR_MAXCH];
+    unsigned int cnt[BFIR_MAXCH];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned long long other = __shfl_xor(bits, o);
-            bits = other > bits ? other : bits;
+    for (int c = 0; c < BFIR_MAXCH; c++) { mx[c] = 0ull; cnt[c] = 0u; }
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long f0 = tl * STAGE_TILE;
+        const int nf = (int)((a.n_frames - f0) < STAGE_TILE ? (a.n_frames - f0) : STAGE_TILE);
+        if (tid < nf) {
+            const long f = f0 + tid;
+            const bool first_of_block = (f % a.L) == 0;
+#pragma unroll
+            for (int c = 0; c < BFIR_MAXCH; c++) {
+                if (c < C) {
+                    const T v = src[(long)c * a.src_ch_stride + f];
+                    tile[tid * C + c] = (TR)v;
+                    // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+                    cnt[c] += ((v < (T)0) ? (v < rmin) : (v > rmax)) ? 1u : 0u;
+                    const unsigned long long bits = (v == v) ? abs_bits(v) : 0ull;
+                    mx[c] = bits > mx[c] ? bits : mx[c];
+                    // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+                    if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+                }
+            }
         }
-        if ((threadIdx.x & 63) == 0) {
-            DevOverflow *of = a.overflow + (e * a.C + c);
-            if (m) atomicAdd(&of->n_overflows, (unsigned int)__popcll(m));
-            if (bits) atomicMax(&of->largest_bits, bits);
+        __syncthreads();
+        if (a.spacing == C) {
+            tile_store(raw + f0 * C, tile, nf * C * (int)sizeof(TR), tid);
+        } else {
+            for (int i = tid; i < nf * C; i += STAGE_TILE) raw[(f0 + i / C) * a.spacing + i % C] = tile[i];
         }
-        // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-        if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+        __syncthreads();
+    }
+    // one filtered atomic per block and channel: the peak only ever grows, so a
+    // stale read of it can cost an extra atomic but never a wrong result
+#pragma unroll
+    for (int c = 0; c < BFIR_MAXCH; c++) {
+        if (c < C) {
+            unsigned long long m = mx[c];
+            unsigned int n = cnt[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long om = __shfl_xor(m, o);
+                m = om > m ? om : m;
+                n += __shfl_xor(n, o);
+            }
+            if ((tid & 63) == 0) { red_max[tid >> 6][c] = m; red_cnt[tid >> 6][c] = n; }
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        unsigned long long m = 0ull;
+        unsigned int n = 0u;
+        for (int w = 0; w < STAGE_TILE / 64; w++) { m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; }
+        DevOverflow *of = a.overflow + (e * C + tid);
+        if (n) atomicAdd(&of->n_overflows, n);
+        if (m > *(volatile unsigned long long *)&of->largest_bits) atomicMax(&of->largest_bits, m);
     }
 }
 
 void launch_stage_out(const StageOutArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
-    dim3 grid((unsigned)((a.n_frames + 255) / 256), a.n_eng), block(256);
+    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
+    dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), a.n_eng), block(STAGE_TILE);
     if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, float>), grid, block, 0, s, a);
     else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_out<double, float>), grid, block, 0, s, a);
     else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, double>), grid, block, 0, s, a);

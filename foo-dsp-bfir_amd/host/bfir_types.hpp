@@ -1,0 +1,45 @@
+// bfir_types.hpp -- the handful of structs that cross the convolver boundary by
+// pointer (brutefir/global.h:39-102).  Inside the reference tree its own
+// global.h provides them (guard _GLOBAL_H_); outside it, these layout-identical
+// definitions do.  The layouts are asserted against include/bfir_hip.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/bfir_hip.h"
+
+#ifndef _GLOBAL_H_
+#define BF_MAXCHANNELS BFIR_MAXCHANNELS
+#define BF_SAMPLE_FORMAT_FLOAT_LE BFIR_SAMPLE_FORMAT_FLOAT_LE
+#define BF_SAMPLE_FORMAT_FLOAT64_LE BFIR_SAMPLE_FORMAT_FLOAT64_LE
+
+struct sample_format_t {
+    bool isfloat, swap;
+    int bytes, sbytes;
+    double scale;
+    int format;
+};
+struct buffer_format_t {
+    sample_format_t sf;
+    int sample_spacing;   // in samples
+    int byte_offset;      // in bytes
+};
+struct dither_state_t;    // integer outputs only; never dereferenced on the float path
+struct bfoverflow_t {
+    unsigned int n_overflows;
+    int32_t intlargest;
+    double largest;
+    double max;
+};
+#endif
+
+static_assert(sizeof(buffer_format_t) == sizeof(bfir_buffer_format), "buffer_format_t layout");
+static_assert(offsetof(buffer_format_t, byte_offset) == offsetof(bfir_buffer_format, byte_offset), "buffer_format_t layout");
+static_assert(sizeof(bfoverflow_t) == sizeof(bfir_overflow), "bfoverflow_t layout");
+static_assert(offsetof(bfoverflow_t, max) == offsetof(bfir_overflow, max), "bfoverflow_t layout");
+
+#ifndef CONVOLVER_MIXMODE_INPUT
+#define CONVOLVER_MIXMODE_INPUT BFIR_MIXMODE_INPUT
+#define CONVOLVER_MIXMODE_INPUT_ADD BFIR_MIXMODE_INPUT_ADD
+#define CONVOLVER_MIXMODE_OUTPUT BFIR_MIXMODE_OUTPUT
+#endif

@@ -14,13 +14,16 @@ echo "== bench default" | tee -a $OUT/progress.log
 timeout -k 10 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo bench failed; tail -20 $OUT/bench_default.err; exit 1; }
 cat $OUT/bench_default.json
 echo "== chunk sweep" | tee -a $OUT/progress.log
-for c in 16 32 64 256 512; do
+for c in 32 64 256 512; do
   timeout -k 10 300 python bench.py --chunk $c --steps 4 --warmup 1 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench_sweep.err || exit 1
+done
+for c in 128 256; do
+  BFIR_MAC_TT=4 timeout -k 10 300 python bench.py --chunk $c --steps 4 --warmup 1 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench_sweep.err || exit 1
 done
 python - <<PY
 import json
 for l in open("$OUT/bench_sweep.jsonl"):
-    d=json.loads(l); print(d["config"]["blocks_per_launch"], d["value"], d["roofline"]["kernel_ms_share"] if d["roofline"] else None)
+    d=json.loads(l); print(d["config"]["blocks_per_launch"], d["value"], d["roofline"]["kernel_ms_share"] if d["roofline"] else None, d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"])
 PY
 echo "== rocprof kernel stats" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/rocprof_stats.log 2>&1 || { tail -20 $OUT/rocprof_stats.log; exit 1; }

@@ -217,10 +217,15 @@ def test_run_device_on_torch_stream(orc, bfir):
     eng = bfir.Brutefir(L, B, s, C); eng.set_chunk(16); eng.set_coeff(h)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
-    st = torch.cuda.current_stream().cuda_stream
-    eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, stream=st)
-    assert eng.sync() == 0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()          # a real (non-null) hipStream_t owned by torch
+    assert side.cuda_stream != 0
+    with torch.cuda.stream(side):
+        eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, stream=side.cuda_stream)
+        done = torch.cuda.Event(); done.record(side)
+    done.synchronize()                  # torch's event sees the work: same runtime, same stream
     assert rel_err(d_out.cpu().numpy(), y_ref) <= TOL[s]
+    assert eng.sync() == 0
 
 
 def test_create_rejects_bad_arguments(bfir):

@@ -4,13 +4,14 @@
 // (brutefir/brutefir.hpp:15-128).  State the reference keeps in host memory
 // (brutefir.cpp:738-810) lives in HBM for the life of the engine:
 //   H     [GC][B][N]        partition spectra        (bfcoeff_t.data, coeff.cpp:292-354)
-//   X     [GC][R][N]        delay line of spectra    (cbuf[n][B]; R >= chunk+B-1 slots)
+//   X     [GC][R][N]        delay line of spectra    (cbuf[n][B]; R = 2*chunk+B slots)
 //   Y     [GC][chunk][N]    accumulated spectra      (ocbuf[n])
-//   tin   [GC][(chunk+1)L]  planar time input, slot 0 = previous block (input_timecbuf)
+//   tin   2 x [GC][chunk*L] planar time input, double buffered (input_timecbuf)
 //   tout  [GC][chunk*L]     planar time output
-//   hist  [2][GC][L]        first halves of input_timecbuf[n][0/1]
+//   saved 2 x [GC][L]      history blocks kept across reset / reallocation
 // GC = n_eng * C global channels.  A run of n blocks is cut into chunks of at
-// most `chunk` blocks; each chunk is five launches on one stream.
+// most `chunk` blocks; each chunk is five launches, the first two on a side
+// stream so that they overlap the last three of the chunk before.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -86,6 +87,12 @@ static int fmt_bytes(int fmt)
     return 0;
 }
 
+// A block of planar time samples somewhere in HBM: [GC][L] with a channel stride.
+struct BlockRef {
+    const void *ptr = nullptr;
+    long ch_stride = 0;   // in reals
+};
+
 struct bfir_engine {
     int device = 0;
     int L = 0, N = 0, B = 0, s = 0, C = 0, n_eng = 1, GC = 0;
@@ -93,17 +100,25 @@ struct bfir_engine {
     double in_scale = 1.0, out_scale = 1.0, of_max = 1.0;
     FftPlan plan;
     int chunk = 0, ring = 0;        // allocated geometry
-    int want_chunk = 64;
-    void *H = nullptr, *X = nullptr, *Y = nullptr, *tin = nullptr, *tout = nullptr, *hist = nullptr;
+    int want_chunk = 128;
+    void *H = nullptr, *X = nullptr, *Y = nullptr, *tout = nullptr;
+    void *tin[2] = {nullptr, nullptr};
+    void *saved[2] = {nullptr, nullptr};   // [GC][L] each: materialised history blocks
+    // first halves of the reference's input_timecbuf[n][0/1] (brutefir.cpp:255-260):
+    // where the block each of them holds currently lives
+    BlockRef hist[2];
     int *d_nblk = nullptr;
     DevOverflow *d_of = nullptr;
     int *d_bad = nullptr;
     std::vector<int> nblk;          // host copy
     std::vector<char> eng_init;     // per engine: coefficients set
     unsigned long long blockcounter = 0;
+    unsigned long long chunk_seq = 0;       // chunks queued since creation
     int curbuf = 0;
-    bool bad_armed = false;
-    hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr;
+    // front (stage_in, fwd) runs on s_front, back (mac, inv, stage_out) on the
+    // caller's stream, so the front of chunk k+1 overlaps the back of chunk k
+    hipStream_t stream = nullptr, s_front = nullptr, s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_fwd[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr};
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
     void *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr};
@@ -120,9 +135,27 @@ struct bfir_engine {
 
 static size_t cbuf_bytes(const bfir_engine *e) { return (size_t)e->N * (size_t)e->s; }
 
+// Copy the two history blocks into the engine-owned `saved` buffers so they
+// survive the work buffers they may point into.  A reference only ever points
+// at its own saved[i] or into a time buffer, never at the other saved buffer.
+static int materialise_history(bfir_engine *e)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t Ls = (size_t)e->L * e->s;
+    for (int i = 0; i < 2; i++) {
+        if (e->hist[i].ptr != e->saved[i])
+            HIP_TRY(hipMemcpy2D(e->saved[i], Ls, e->hist[i].ptr, (size_t)e->hist[i].ch_stride * e->s, Ls, e->GC,
+                                hipMemcpyDeviceToDevice));
+        e->hist[i].ptr = e->saved[i];
+        e->hist[i].ch_stride = e->L;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return BFIR_OK;
+}
+
 static void free_work(bfir_engine *e)
 {
-    void **bufs[] = {&e->X, &e->Y, &e->tin, &e->tout};
+    void **bufs[] = {&e->X, &e->Y, &e->tin[0], &e->tin[1], &e->tout};
     for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     for (int i = 0; i < 2; i++) {
         if (e->pin_in[i]) (void)hipHostFree(e->pin_in[i]);
@@ -136,31 +169,34 @@ static void free_work(bfir_engine *e)
 }
 
 // (Re)allocate the chunk-sized work buffers.  The delay line is carried over
-// slot by slot when the ring size changes.
+// slot by slot when the ring size changes; the time history is moved into
+// `saved` first because it may live in the buffers being freed.
 static int alloc_work(bfir_engine *e, int chunk)
 {
     const size_t cb = cbuf_bytes(e);
-    const int ring = chunk + e->B;  // >= chunk + B - 1
-    void *X = nullptr, *Y = nullptr, *tin = nullptr, *tout = nullptr;
+    // fwd of chunk k+1 may run while mac of chunk k still reads its B-1 older slots
+    const int ring = 2 * chunk + e->B;
+    if (e->X) { int rc = materialise_history(e); if (rc != BFIR_OK) return rc; }
+    void *X = nullptr, *Y = nullptr, *tin0 = nullptr, *tin1 = nullptr, *tout = nullptr;
     HIP_TRY(hipMalloc(&X, (size_t)e->GC * ring * cb));
     HIP_TRY(hipMalloc(&Y, (size_t)e->GC * chunk * cb));
-    HIP_TRY(hipMalloc(&tin, (size_t)e->GC * (chunk + 1) * e->L * e->s));
+    HIP_TRY(hipMalloc(&tin0, (size_t)e->GC * chunk * e->L * e->s));
+    HIP_TRY(hipMalloc(&tin1, (size_t)e->GC * chunk * e->L * e->s));
     HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
-    HIP_TRY(hipMemsetAsync(X, 0, (size_t)e->GC * ring * cb, e->stream));
-    HIP_TRY(hipMemsetAsync(tin, 0, (size_t)e->GC * (chunk + 1) * e->L * e->s, e->stream));
+    HIP_TRY(hipMemset(X, 0, (size_t)e->GC * ring * cb));
     if (e->X) {
         // keep the last B-1 spectra: absolute block j lives in slot j % ring
         const int keep = (int)std::min<unsigned long long>(e->blockcounter, (unsigned long long)(e->B - 1));
         for (int d = 1; d <= keep; d++) {
             const unsigned long long j = e->blockcounter - d;
             const size_t so = (size_t)(j % e->ring) * cb, dn = (size_t)(j % ring) * cb;
-            HIP_TRY(hipMemcpy2DAsync((char *)X + dn, (size_t)ring * cb, (char *)e->X + so,
-                                     (size_t)e->ring * cb, cb, e->GC, hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemcpy2D((char *)X + dn, (size_t)ring * cb, (char *)e->X + so, (size_t)e->ring * cb, cb,
+                                e->GC, hipMemcpyDeviceToDevice));
         }
-        HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    HIP_TRY(hipDeviceSynchronize());
     free_work(e);
-    e->X = X; e->Y = Y; e->tin = tin; e->tout = tout;
+    e->X = X; e->Y = Y; e->tin[0] = tin0; e->tin[1] = tin1; e->tout = tout;
     e->chunk = chunk; e->ring = ring;
     return BFIR_OK;
 }
@@ -200,24 +236,26 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
     if (rc != 0) { *err = (rc == -1) ? BFIR_ERR_UNSUPPORTED : BFIR_ERR_HIP; delete e; return nullptr; }
     auto fail = [&](int code) { *err = code; bfir_engine_destroy(e); return (bfir_engine *)nullptr; };
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
-    if (hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
-    if (hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
-    for (int i = 0; i < 2; i++) {
-        if (hipEventCreateWithFlags(&e->ev_h2d[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_comp[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_d2h[i], hipEventDisableTiming) != hipSuccess)
-            return fail(BFIR_ERR_HIP);
-    }
-    const size_t cb = cbuf_bytes(e);
+    hipStream_t *streams[] = {&e->stream, &e->s_front, &e->s_in, &e->s_out};
+    for (hipStream_t *st : streams)
+        if (hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
+    hipEvent_t *events[] = {&e->ev_entry, &e->ev_fwd[0], &e->ev_fwd[1], &e->ev_mac[0], &e->ev_mac[1],
+                            &e->ev_h2d[0], &e->ev_h2d[1], &e->ev_comp[0], &e->ev_comp[1], &e->ev_d2h[0], &e->ev_d2h[1]};
+    for (hipEvent_t *ev : events)
+        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return fail(BFIR_ERR_HIP);
+    const size_t cb = cbuf_bytes(e), Ls = (size_t)e->L * e->s;
     if (hipMalloc(&e->H, (size_t)e->GC * e->B * cb) != hipSuccess ||
-        hipMalloc(&e->hist, (size_t)2 * e->GC * e->L * e->s) != hipSuccess ||
+        hipMalloc(&e->saved[0], (size_t)e->GC * Ls) != hipSuccess ||
+        hipMalloc(&e->saved[1], (size_t)e->GC * Ls) != hipSuccess ||
         hipMalloc((void **)&e->d_nblk, sizeof(int) * e->GC) != hipSuccess ||
         hipMalloc((void **)&e->d_of, sizeof(DevOverflow) * e->GC) != hipSuccess ||
         hipMalloc((void **)&e->d_bad, sizeof(int)) != hipSuccess)
         return fail(BFIR_ERR_HIP);
     (void)hipMemset(e->H, 0, (size_t)e->GC * e->B * cb);
-    (void)hipMemset(e->hist, 0, (size_t)2 * e->GC * e->L * e->s);
+    for (int i = 0; i < 2; i++) {   // input_timecbuf starts zeroed (brutefir.cpp:769)
+        (void)hipMemset(e->saved[i], 0, (size_t)e->GC * Ls);
+        e->hist[i].ptr = e->saved[i]; e->hist[i].ch_stride = e->L;
+    }
     (void)hipMemset(e->d_nblk, 0, sizeof(int) * e->GC);
     (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
     (void)hipMemset(e->d_bad, 0x7f, sizeof(int));
@@ -243,18 +281,15 @@ extern "C" void bfir_engine_destroy(bfir_engine *e)
     (void)hipDeviceSynchronize();
     free_work(e);
     fft_plan_destroy(&e->plan);
-    void *bufs[] = {e->H, e->hist, e->d_nblk, e->d_of, e->d_bad};
+    void *bufs[] = {e->H, e->saved[0], e->saved[1], e->d_nblk, e->d_of, e->d_bad};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto &sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 2; i++) {
-        if (e->ev_h2d[i]) (void)hipEventDestroy(e->ev_h2d[i]);
-        if (e->ev_comp[i]) (void)hipEventDestroy(e->ev_comp[i]);
-        if (e->ev_d2h[i]) (void)hipEventDestroy(e->ev_d2h[i]);
-    }
-    if (e->stream) (void)hipStreamDestroy(e->stream);
-    if (e->s_in) (void)hipStreamDestroy(e->s_in);
-    if (e->s_out) (void)hipStreamDestroy(e->s_out);
+    hipEvent_t events[] = {e->ev_entry, e->ev_fwd[0], e->ev_fwd[1], e->ev_mac[0], e->ev_mac[1],
+                           e->ev_h2d[0], e->ev_h2d[1], e->ev_comp[0], e->ev_comp[1], e->ev_d2h[0], e->ev_d2h[1]};
+    for (hipEvent_t ev : events) if (ev) (void)hipEventDestroy(ev);
+    hipStream_t streams[] = {e->stream, e->s_front, e->s_in, e->s_out};
+    for (hipStream_t st : streams) if (st) (void)hipStreamDestroy(st);
     delete e;
 }
 
@@ -279,7 +314,7 @@ extern "C" int bfir_engine_set_coeff_at(bfir_engine *e, int engine_index, const 
     if (!e || engine_index < 0 || engine_index >= e->n_eng || !coeffs || length < 0 || coeff_blocks < 1)
         return BFIR_ERR_ARG;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipDeviceSynchronize());
     e->eng_init[engine_index] = 0;                              // free_coeff(), brutefir.cpp:188
     if (n_coeffs > e->C) n_coeffs = e->C;                       // brutefir.cpp:190-193
     const int nb = std::min(coeff_blocks, e->B);                // run() never looks past B blocks
@@ -313,9 +348,9 @@ extern "C" int bfir_engine_set_coeff_at(bfir_engine *e, int engine_index, const 
     HIP_TRY(hipMemcpyAsync(d_taps, host.data(), host.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync((char *)e->H + (size_t)gc0 * e->B * cb, 0, (size_t)e->C * e->B * cb, e->stream));
     FwdArgs fa;
-    // window of block b = [L zeros | taps b*L .. b*L+L): start the window L before the block
-    fa.src = (const char *)d_taps - (size_t)e->L * e->s;
-    fa.src_ch_stride = (long)taps_pad;
+    // window of block b = [L zeros | taps b*L .. b*L+L)
+    fa.src = d_taps; fa.src_ch_stride = (long)taps_pad;
+    fa.prev = nullptr; fa.prev_ch_stride = 0;
     fa.dst = (char *)e->H + (size_t)gc0 * e->B * cb;
     fa.dst_ch_stride = (long)e->B * e->N;
     fa.ring = e->B; fa.base_slot = 0;
@@ -344,7 +379,7 @@ extern "C" int bfir_engine_read_coeff(bfir_engine *e, int channel, int block, vo
 {
     if (!e || channel < 0 || channel >= e->GC || block < 0 || block >= e->B || !dst) return BFIR_ERR_ARG;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipDeviceSynchronize());
     const size_t cb = cbuf_bytes(e);
     HIP_TRY(hipMemcpy(dst, (char *)e->H + ((size_t)channel * e->B + block) * cb, cb, hipMemcpyDeviceToHost));
     return BFIR_OK;
@@ -396,6 +431,9 @@ extern "C" int bfir_engine_set_profiling(bfir_engine *e, int enable)
     if (!e) return BFIR_ERR_ARG;
     drain_spans(e);
     e->profiling = enable != 0;
+    if (e->profiling && e->ev_pool.size() < 4096) {   // keep event creation out of timed regions
+        for (int i = 0; i < 4096; i++) { hipEvent_t ev = nullptr; if (hipEventCreate(&ev) == hipSuccess) e->ev_pool.push_back(ev); }
+    }
     for (int k = 0; k < BFIR_K_COUNT; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
     return BFIR_OK;
 }
@@ -410,41 +448,54 @@ extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total
 }
 
 // ---------------------------------------------------------------------------
-// brutefir::run, chunked
+// brutefir::run, chunked and software-pipelined over two streams
 // ---------------------------------------------------------------------------
-// Queue one chunk of tc blocks (frames frame_off .. of every engine's raw buffer).
+// Queue one chunk of tc blocks (frames frame_off .. of every engine's raw
+// buffer).  `st` is the caller's stream: the input must be ready on it when
+// this is called, and the output is complete on it when its work is.
+//   s_front : stage_in(k) -> fwd(k)                      (k = chunk sequence number)
+//   st      : mac(k) -> inv(k) -> stage_out(k)
+// fwd(k) writes delay-line slots that mac(k-2) may still read (ring = 2*chunk+B),
+// and stage_in(k) rewrites the time buffer fwd(k-2) read; both are ordered by
+// events / stream order, so front(k+1) overlaps back(k).
 static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
-                     long frame_off, int tc, int block_base, hipStream_t st)
+                     long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
 {
-    const size_t Ls = (size_t)e->L * e->s;
-    const long tin_stride = (long)(e->chunk + 1) * e->L, tout_stride = (long)e->chunk * e->L;
-    const size_t hist_plane = (size_t)e->GC * Ls;
-    // previous block as the reference sees it: first half of input_timecbuf[n][curbuf]
-    // (fftw_convolver.cpp:184 leaves it there one call earlier)
-    HIP_TRY(hipMemcpy2DAsync(e->tin, (size_t)tin_stride * e->s, (char *)e->hist + e->curbuf * hist_plane,
-                             Ls, Ls, e->GC, hipMemcpyDeviceToDevice, st));
+    const int par = (int)(e->chunk_seq & 1);
+    const long t_stride = (long)e->chunk * e->L;
+    void *tin = e->tin[par];
+    const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
+    hipStream_t sf = e->s_front;
+
+    // the front only waits for the input, never for the back of the chunk before
+    if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
     {
-        ProfScope ps(e, BFIR_K_STAGE_IN, st);
+        ProfScope ps(e, BFIR_K_STAGE_IN, sf);
         StageInArgs a;
         a.raw = d_in; a.eng_stride_bytes = in_stride; a.frame_off = frame_off;
         a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->in_bytes; a.spacing = e->C;
         a.n_frames = (long)tc * e->L;
-        a.dst = e->tin; a.dst_ch_stride = tin_stride; a.dst_off = e->L;
+        a.dst = tin; a.dst_ch_stride = t_stride; a.dst_off = 0;
         a.realsize = e->s;
-        launch_stage_in(a, st);
+        launch_stage_in(a, sf);
     }
-    const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
+    if (e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
     {
-        ProfScope ps(e, BFIR_K_FWD, st);
+        ProfScope ps(e, BFIR_K_FWD, sf);
         FwdArgs a;
-        a.src = e->tin; a.src_ch_stride = tin_stride;
+        a.src = tin; a.src_ch_stride = t_stride;
+        // the block before this chunk, as the reference sees it: first half of
+        // input_timecbuf[n][curbuf] (fftw_convolver.cpp:184 left it there one call earlier)
+        a.prev = e->hist[e->curbuf].ptr; a.prev_ch_stride = e->hist[e->curbuf].ch_stride;
         a.dst = e->X; a.dst_ch_stride = (long)e->ring * e->N;
         a.ring = e->ring; a.base_slot = base_slot;
         a.n_t = tc; a.n_ch = e->GC;
         a.load_scale = 1.0; a.out_scale = e->in_scale;
         a.zero_first_half = 0;
-        launch_fwd(e->plan, a, st);
+        launch_fwd(e->plan, a, sf);
     }
+    HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
+    HIP_TRY(hipStreamWaitEvent(st, e->ev_fwd[par], 0));
     {
         ProfScope ps(e, BFIR_K_MAC, st);
         MacArgs a;
@@ -455,11 +506,12 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s;
         launch_mac(a, st);
     }
+    HIP_TRY(hipEventRecord(e->ev_mac[par], st));
     {
         ProfScope ps(e, BFIR_K_INV, st);
         InvArgs a;
         a.src = e->Y; a.src_ch_stride = (long)e->chunk * e->N;
-        a.dst = e->tout; a.dst_ch_stride = tout_stride;
+        a.dst = e->tout; a.dst_ch_stride = t_stride;
         a.n_t = tc; a.n_ch = e->GC;
         a.in_scale = e->out_scale;
         a.full_output = 0;
@@ -471,32 +523,29 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.raw = d_out; a.eng_stride_bytes = out_stride; a.frame_off = frame_off;
         a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->out_bytes; a.spacing = e->C;
         a.n_frames = (long)tc * e->L;
-        a.src = e->tout; a.src_ch_stride = tout_stride;
+        a.src = e->tout; a.src_ch_stride = t_stride;
         a.realsize = e->s; a.L = e->L; a.max = e->of_max;
         a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
         launch_stage_out(a, st);
     }
-    // input_timecbuf bookkeeping: block j of the chunk is written into buffer
-    // !(curbuf ^ (j & 1)); keep the last two blocks where the reference has them.
+    // input_timecbuf bookkeeping: block j of the chunk lands in buffer
+    // !(curbuf ^ (j & 1)).  Only the references move; the samples stay where
+    // stage_in put them (this time buffer is not rewritten before chunk k+2,
+    // by which time both references have moved on).
+    const size_t Ls = (size_t)e->L * e->s;
     const int idx_last = 1 ^ e->curbuf ^ ((tc - 1) & 1);
-    if (tc >= 2)
-        HIP_TRY(hipMemcpy2DAsync((char *)e->hist + (1 ^ idx_last) * hist_plane, Ls,
-                                 (char *)e->tin + (size_t)(tc - 1) * Ls, (size_t)tin_stride * e->s, Ls,
-                                 e->GC, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpy2DAsync((char *)e->hist + idx_last * hist_plane, Ls, (char *)e->tin + (size_t)tc * Ls,
-                             (size_t)tin_stride * e->s, Ls, e->GC, hipMemcpyDeviceToDevice, st));
+    if (tc >= 2) { e->hist[1 ^ idx_last].ptr = (char *)tin + (size_t)(tc - 2) * Ls; e->hist[1 ^ idx_last].ch_stride = t_stride; }
+    e->hist[idx_last].ptr = (char *)tin + (size_t)(tc - 1) * Ls; e->hist[idx_last].ch_stride = t_stride;
     e->curbuf ^= (tc & 1);
     e->blockcounter += (unsigned long long)tc;
+    e->chunk_seq += 1;
     return BFIR_OK;
 }
 
 static int ensure_chunk(bfir_engine *e, int n_blocks)
 {
     const int want = std::max(1, std::min(e->want_chunk, n_blocks));
-    if (want > e->chunk) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        return alloc_work(e, want);
-    }
+    if (want > e->chunk) return alloc_work(e, want);
     return BFIR_OK;
 }
 
@@ -510,9 +559,12 @@ extern "C" int bfir_engine_run_device(bfir_engine *e, const void *d_in, long in_
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     int rc = ensure_chunk(e, n_blocks);
     if (rc != BFIR_OK) return rc;
+    // whatever produced d_in on the caller's stream must be done before the front reads it
+    HIP_TRY(hipEventRecord(e->ev_entry, st));
     for (int c0 = 0; c0 < n_blocks; c0 += e->chunk) {
         const int tc = std::min(e->chunk, n_blocks - c0);
-        rc = run_chunk(e, d_in, in_stride_bytes, d_out, out_stride_bytes, (long)c0 * e->L, tc, c0, st);
+        rc = run_chunk(e, d_in, in_stride_bytes, d_out, out_stride_bytes, (long)c0 * e->L, tc, c0, st,
+                       c0 == 0 ? e->ev_entry : nullptr);
         if (rc != BFIR_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -555,8 +607,10 @@ static int ensure_staging(bfir_engine *e)
     return BFIR_OK;
 }
 
-// Host-pointer run: pinned double buffers, H2D on s_in, kernels on stream,
-// D2H on s_out, so the copies of neighbouring chunks overlap the compute.
+// Host-pointer run: pinned double buffers, H2D on s_in, kernels on the engine's
+// streams, D2H on s_out, so the copies of neighbouring chunks overlap the compute
+// (the reference's raw2real / real2raw staging, fftw_convolver.cpp:156-185, 405-466,
+// turned into pinned-host staging).
 extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, int n_blocks)
 {
     if (!e || !inbuf || !outbuf || n_blocks < 0) return BFIR_ERR_ARG;
@@ -586,8 +640,8 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
             memcpy((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
         HIP_TRY(hipMemcpyAsync(e->dev_in[b], e->pin_in[b], per_in * e->n_eng, hipMemcpyHostToDevice, e->s_in));
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->s_in));
-        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
-        rc = run_chunk(e, e->dev_in[b], (long)per_in, e->dev_out[b], (long)per_out, 0, tc, c0, e->stream);
+        rc = run_chunk(e, e->dev_in[b], (long)per_in, e->dev_out[b], (long)per_out, 0, tc, c0, e->stream,
+                       e->ev_h2d[b]);
         if (rc != BFIR_OK) return rc;
         HIP_TRY(hipEventRecord(e->ev_comp[b], e->stream));
         HIP_TRY(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
@@ -604,12 +658,14 @@ extern "C" void bfir_engine_reset(bfir_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipDeviceSynchronize();
     // brutefir.cpp:346-367: counters only.  procblocks = 0 hides every
     // delay-line slot written before the reset (brutefir.cpp:292), which the
-    // zeroed ring reproduces; the time-domain history is NOT cleared.
+    // zeroed ring reproduces; the time-domain history is NOT cleared, so both
+    // input_timecbuf halves are kept (copied out of the work buffers).
+    (void)materialise_history(e);
     (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
     (void)hipMemset(e->X, 0, (size_t)e->GC * e->ring * cbuf_bytes(e));
+    (void)hipDeviceSynchronize();
     e->blockcounter = 0;
     e->curbuf = 0;
 }

@@ -56,10 +56,13 @@ struct StageOutArgs {
 void launch_stage_out(const StageOutArgs &a, hipStream_t s);
 
 // a6 + a7 (and a16 with zero_first_half): real FFT of the N-sample window
-// starting at src + gc*src_ch_stride + t*L, written in the grouped layout to
-// dst + gc*dst_ch_stride + ((base_slot + t) % ring) * N.
+// [block t-1 | block t] of channel gc, written in the grouped layout to
+// dst + gc*dst_ch_stride + ((base_slot + t) % ring) * N.  Block t (t >= 0) is
+// at src + gc*src_ch_stride + t*L; the block before block 0 is at
+// prev + gc*prev_ch_stride.
 struct FwdArgs {
     const void *src; long src_ch_stride;
+    const void *prev; long prev_ch_stride;
     void *dst; long dst_ch_stride;
     int ring, base_slot;
     int n_t, n_ch;

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
 
     const int tid = threadIdx.x;
     const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
-    const T *__restrict__ src = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * M;
+    const T *__restrict__ cur = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * M;
+    const T *__restrict__ old = (t == 0) ? (const T *)a.prev + (long)gc * a.prev_ch_stride : cur - M;
     T *__restrict__ dst =
         (T *)a.dst + (long)gc * a.dst_ch_stride + (long)((a.base_slot + t) % a.ring) * N;
 
@@ -133,10 +134,15 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
 #pragma unroll
     for (int e = 0; e < P; e++) {
         const int m = F::in_index(tid, e);
-        if (a.zero_first_half && m < M / 2) {
-            re[e] = (T)0; im[e] = (T)0;
+        if (m < M / 2) {
+            if (a.zero_first_half) {
+                re[e] = (T)0; im[e] = (T)0;
+            } else {
+                V2 v = *(const V2 *)(old + 2 * m);
+                re[e] = v.x * ls; im[e] = v.y * ls;
+            }
         } else {
-            V2 v = *(const V2 *)(src + 2 * m);
+            V2 v = *(const V2 *)(cur + (2 * m - M));
             re[e] = v.x * ls; im[e] = v.y * ls;
         }
     }
@@ -567,6 +573,7 @@ void launch_stage_out(const StageOutArgs &a, hipStream_t s)
 template <typename T>
 __global__ void k_reorder(const T *__restrict__ in, T *__restrict__ out, int n_fft, T sc, int to_grouped)
 {
+#pragma clang fp contract(off)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int half = n_fft >> 1;
     if (k >= half) return;
@@ -596,14 +603,23 @@ void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_g
 // ---------------------------------------------------------------------------
 // stage API: one complex multiply(-add) pass in the reference's operation order
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+// separately rounded multiply / add: the pragma strips the `contract` flag the
+// -ffp-contract=fast build would otherwise put on these operations
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 template <typename T>
 __global__ void k_cmul_stage(const T *b, const T *c, T *d, int n_fft, int mode)
 {
+#pragma clang fp contract(off)   // keep every multiply and add separately rounded
     // one thread per bin; brutefir/fftw_convolver.cpp:1464-1525 (float), :2160-2220 (double)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (n_fft >> 1)) return;

@@ -143,7 +143,9 @@ extern "C" int bfir_convolver_time2freq(bfir_convolver *c, const void *input_cbu
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d[0], input_cbuf, cb(c), hipMemcpyHostToDevice, c->stream));
     FwdArgs a;
-    a.src = c->d[0]; a.src_ch_stride = 0; a.dst = c->d[1]; a.dst_ch_stride = 0;
+    a.prev = c->d[0]; a.prev_ch_stride = 0;
+    a.src = (char *)c->d[0] + (size_t)c->L * c->s; a.src_ch_stride = 0;
+    a.dst = c->d[1]; a.dst_ch_stride = 0;
     a.ring = 1; a.base_slot = 0; a.n_t = 1; a.n_ch = 1;
     a.load_scale = 1.0; a.out_scale = 1.0; a.zero_first_half = 0;
     launch_fwd(c->plan, a, c->stream);
@@ -269,10 +271,11 @@ extern "C" void *bfir_convolver_coeffs2cbuf(bfir_convolver *c, const void *coeff
             if (!std::isfinite(src[n] * scale)) { bfir_logf("NaN or Inf value among coefficients.\n"); return nullptr; }
     }
     if (len > 0) memcpy(taps.data(), coeffs, (size_t)len * c->s);
-    // window = [L zeros | taps]: put the taps in the upper half of d[0]
-    if (hipMemcpyAsync((char *)c->d[0] + (size_t)c->L * c->s, taps.data(), taps.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    // window = [L zeros | taps]
+    if (hipMemcpyAsync(c->d[0], taps.data(), taps.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess)
         return nullptr;
     FwdArgs a;
+    a.prev = nullptr; a.prev_ch_stride = 0;
     a.src = c->d[0]; a.src_ch_stride = 0; a.dst = c->d[1]; a.dst_ch_stride = 0;
     a.ring = 1; a.base_slot = 0; a.n_t = 1; a.n_ch = 1;
     a.load_scale = scale; a.out_scale = 1.0 / (double)c->N; a.zero_first_half = 1;

@@ -49,6 +49,22 @@ def algorithmic_bytes_per_block(C, B, N, L, s):
     }
 
 
+def measured_traffic(kernel, workload, chunk):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_*.json,
+    written by scripts/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command), or None when no pass matches this workload and blocks-per-launch."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        m = d.get("meta", {})
+        if m.get("workload") == workload and int(m.get("chunk", -1)) == int(chunk) and kernel in d["per_launch"]:
+            return d["per_launch"][kernel]["total_bytes"]
+    return None
+
+
 def cpu_baseline(O, C, taps, L, B, s, h, x, budget_s=12.0):
     """Time the oracle (1 thread) on a bounded sample: B warm-up blocks, then blocks until ~budget."""
     eng = O.Engine(L, B, s, C)
@@ -75,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=1024, help="blocks per step")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "128")),
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "256")),
                     help="blocks per kernel launch")
     ap.add_argument("--workload", default="cfg3_8ch_131072tap_L4096_fp32", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +180,7 @@ def main():
             achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None,
+                        "traffic": measured_traffic(dom, args.workload, args.chunk),
                         "algorithmic_bytes_per_launch": int(alg[dom] * blocks_per_launch),
                         "avg_launch_ms": round(ms / launches, 5),
                         "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)

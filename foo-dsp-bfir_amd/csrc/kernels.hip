@@ -310,9 +310,10 @@ template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, con
     ar.w = fma(xr.w, hr.w, ar.w); ar.w = fma(-xi.w, hi.w, ar.w); ai.w = fma(xr.w, hi.w, ai.w); ai.w = fma(xi.w, hr.w, ai.w);
 }
 
-template <typename T, int TT, int WPE>
+template <typename T, int TT, int WPE, int D>
 __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, int G)
 {
+    static_assert(D >= 1 && TT % D == 0, "prefetch depth must divide the time tile");
     using V4 = typename Vec4<T>::type;
     // XCD-aware, bijective block -> work remap: each XCD (blocks b, b+8, ...)
     // gets one contiguous range of work items, ordered (channel, bin tile)
@@ -344,24 +345,36 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
         int sj = sl + j; if (sj >= ring) sj -= ring;
         wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
     }
-    V4 hr = H[0], hi = H[1];
     // Partitions in the reference's order i = 0 .. nb-1, TT per trip so the
-    // rotating window keeps compile-time register names.  Every step first
-    // issues the loads of the NEXT step (partition i+1 and the one new
-    // delay-line spectrum X[t0-i-1]), then does its TT x 4 complex MACs, so a
-    // whole step of arithmetic covers the load latency.
+    // rotating window keeps compile-time register names.  Operands are fetched
+    // D steps ahead into a small register queue: step i consumes H_i and the
+    // one new delay-line spectrum X[t0-i] (entering the window in place of the
+    // entry nobody needs any more) from queue slot i mod D, refills that slot
+    // with the operands of step i+D, then does its TT x 4 complex MACs, so D
+    // steps of arithmetic cover the load latency.
+    V4 qhr[D], qhi[D], qxr[D], qxi[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int ih = d < nb ? d : nb - 1;
+        qhr[d] = H[ih * slot4]; qhi[d] = H[ih * slot4 + 1];
+        int sd = sl - d; if (sd < 0) sd += ring;       // slot of X[t0 - d]; d = 0 is never consumed
+        qxr[d] = X[sd * slot4]; qxi[d] = X[sd * slot4 + 1];
+    }
+    int sp = sl - D; if (sp < 0) sp += ring;           // slot of X[t0 - (i + D)] for i = 0
     for (int i0 = 0; i0 < nb; i0 += TT) {
 #pragma unroll
         for (int ii = 0; ii < TT; ii++) {
             const int i = i0 + ii;
             if (i < nb) {   // wave-uniform
-                const int in = (i + 1 < nb) ? i + 1 : i;
-                const V4 hrn = H[in * slot4], hin = H[in * slot4 + 1];
-                sl -= 1; if (sl < 0) sl += ring;
-                const V4 xrn = X[sl * slot4], xin = X[sl * slot4 + 1];
+                constexpr int TTc = TT;
+                const V4 hr = qhr[ii % D], hi = qhi[ii % D];
+                if (i > 0) { wr[(TTc - ii) % TTc] = qxr[ii % D]; wi[(TTc - ii) % TTc] = qxi[ii % D]; }
+                const int ih = (i + D < nb) ? i + D : nb - 1;
+                qhr[ii % D] = H[ih * slot4]; qhi[ii % D] = H[ih * slot4 + 1];
+                qxr[ii % D] = X[sp * slot4]; qxi[ii % D] = X[sp * slot4 + 1];
+                sp -= 1; if (sp < 0) sp += ring;
 #pragma unroll
                 for (int j = 0; j < TT; j++) {
-                    constexpr int TTc = TT;
                     const int idx = (j - ii + TTc) % TTc;  // window slot holding X[t0 + j - i]
                     cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
                     if (wave0) {
@@ -369,8 +382,6 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
                         ny[j] = fma(wi[idx].x, hi.x, ny[j]);
                     }
                 }
-                wr[TT - 1 - ii] = xrn; wi[TT - 1 - ii] = xin;  // X[t0-i-1] replaces the entry nobody needs any more
-                hr = hrn; hi = hin;
             }
         }
     }
@@ -386,42 +397,47 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
     }
 }
 
-template <typename T, int TT, int WPE> static void launch_mac_t(const MacArgs &a, hipStream_t s)
+template <typename T, int TT, int WPE, int D> static void launch_mac_t(const MacArgs &a, hipStream_t s)
 {
     const int G = a.N / 8;
     const int threads = G < 256 ? G : 256;
     const int nbt = (G + threads - 1) / threads;
     const int nTT = (a.n_t + TT - 1) / TT;
     const int W = nTT * nbt * a.n_ch;
-    hipLaunchKernelGGL((k_mac<T, TT, WPE>), dim3(W), dim3(threads), 0, s, a, nbt, nTT, G);
+    hipLaunchKernelGGL((k_mac<T, TT, WPE, D>), dim3(W), dim3(threads), 0, s, a, nbt, nTT, G);
 }
 
-// BFIR_MAC_TT (tuning aid): cap the time tile of the MAC kernel.
-static int mac_tt_cap()
+// BFIR_MAC_VARIANT (tuning aid): pick another (time tile, waves/SIMD, prefetch depth)
+// instantiation of the fp32 MAC kernel.  All variants give bit-identical results.
+static int mac_variant()
 {
-    static int cap = -1;
-    if (cap < 0) {
-        const char *e = getenv("BFIR_MAC_TT");
-        cap = e ? atoi(e) : 0;
-        if (cap <= 0) cap = 1 << 30;
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("BFIR_MAC_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
     }
-    return cap;
+    return v;
 }
 
 void launch_mac(const MacArgs &a, hipStream_t s)
 {
     if (a.n_t <= 0 || a.n_ch <= 0) return;
-    const int cap = mac_tt_cap();
-    const int tt = a.n_t < cap ? a.n_t : cap;
+    const int tt = a.n_t;
     if (a.realsize == 4) {
-        if (tt >= 8) launch_mac_t<float, 8, 2>(a, s);
-        else if (tt >= 4) launch_mac_t<float, 4, 3>(a, s);
-        else if (tt >= 2) launch_mac_t<float, 2, 4>(a, s);
-        else launch_mac_t<float, 1, 4>(a, s);
+        const int v = mac_variant();
+        if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);
+        else if (tt >= 16 && v == 3) launch_mac_t<float, 16, 1, 4>(a, s);
+        else if (tt >= 8 && v == 1) launch_mac_t<float, 8, 2, 1>(a, s);
+        else if (tt >= 4 && v == 4) launch_mac_t<float, 4, 3, 2>(a, s);
+        else if (tt >= 8) launch_mac_t<float, 8, 2, 2>(a, s);   // measured best (profiles/r01_mac_variants.txt)
+        else if (tt >= 4) launch_mac_t<float, 4, 3, 1>(a, s);
+        else if (tt >= 2) launch_mac_t<float, 2, 4, 1>(a, s);
+        else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
-        if (tt >= 4) launch_mac_t<double, 4, 2>(a, s);
-        else if (tt >= 2) launch_mac_t<double, 2, 3>(a, s);
-        else launch_mac_t<double, 1, 4>(a, s);
+        if (tt >= 4) launch_mac_t<double, 4, 2, 1>(a, s);
+        else if (tt >= 2) launch_mac_t<double, 2, 3, 1>(a, s);
+        else launch_mac_t<double, 1, 4, 1>(a, s);
     }
 }
 

@@ -35,6 +35,7 @@ WORKLOADS = {
     "cfg3_8ch_131072tap_L4096_fp32": (8, 131072, 4096, 4),
     "cfg2_2ch_65536tap_L8192_fp32": (2, 65536, 8192, 4),
     "cfg5_2ch_262144tap_L4096_fp64": (2, 262144, 4096, 8),
+    "cfg4_stereo_65536tap_L4096_fp32": (2, 65536, 4096, 4),   # per stream; use with --streams
 }
 
 
@@ -94,6 +95,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "256")),
                     help="blocks per kernel launch")
     ap.add_argument("--workload", default="cfg3_8ch_131072tap_L4096_fp32", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0,
+                    help="total independent engines dealt out to the ranks (0 = one per rank); "
+                         "configs[3]: --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region")
@@ -116,30 +120,49 @@ def main():
 
     import foo_dsp_bfir_amd as bfir   # raises if the HIP library is missing
 
+    from foo_dsp_bfir_amd import sharding
+
     C, taps, L, s = WORKLOADS[args.workload]
     N, B = 2 * L, (taps + L - 1) // L
     rdt = np.float32 if s == 4 else np.float64
-    tdt = torch.float32 if s == 4 else torch.float64
     nb = args.blocks
+    # Units = independent engines (streams).  Headline: one 8-channel engine per GPU (weak
+    # scaling).  --streams S: S engines in total, dealt out to the ranks (strong scaling,
+    # BASELINE.json configs[3] with S = 256); no rank ever exchanges audio with another.
+    if args.streams > 0:
+        lo, hi = sharding.shard_range(args.streams, rank, world)
+        n_eng, first_stream, scaling = hi - lo, lo, "strong"
+    else:
+        n_eng, first_stream, scaling = 1, rank, "weak"
 
-    # synthetic audio / IR of SURVEY.md 8(d); every rank has its own stream
-    rng = np.random.default_rng(3 + 1000 * rank)
+    # synthetic audio / IR of SURVEY.md 8(d); stream k is the same whichever rank owns it
     n = np.arange(taps, dtype=np.float64)
-    h = []
-    for _ in range(C):
-        v = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n / taps)
-        h.append((v / np.abs(v).sum()).astype(rdt))
-    x_host = rng.uniform(-1.0, 1.0, (nb * L, C)).astype(rdt)
+    hs, xs = [], []
+    for k in range(first_stream, first_stream + n_eng):
+        rng = np.random.default_rng(3 + 1000 * k)
+        h = []
+        for _ in range(C):
+            v = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n / taps)
+            h.append((v / np.abs(v).sum()).astype(rdt))
+        hs.append(h)
+        xs.append(rng.uniform(-1.0, 1.0, (nb * L, C)).astype(rdt))
+    h, x_host = (hs[0], xs[0]) if n_eng else (None, None)
 
-    eng = bfir.Brutefir(L, B, s, C, device=local)
-    eng.set_chunk(args.chunk)
-    assert eng.set_coeff(h) == 0
-    d_in = torch.from_numpy(x_host).to(dev)
-    d_out = torch.empty_like(d_in)
+    eng = d_in = d_out = None
+    if n_eng:
+        eng = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
+        eng.set_chunk(args.chunk)
+        for k in range(n_eng):
+            assert eng.set_coeff(hs[k], engine_index=k) == 0
+        d_in = torch.from_numpy(np.stack(xs)).to(dev)       # [n_eng, nb*L, C]
+        d_out = torch.empty_like(d_in)
+    eng_stride = nb * L * C * (4 if s == 4 else 8)
     stream = torch.cuda.current_stream()
 
     def step():
-        eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, stream=stream.cuda_stream)
+        if eng is not None:
+            eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=eng_stride,
+                           out_stride_bytes=eng_stride, stream=stream.cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -149,25 +172,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    assert eng.sync() == 0
-    eng.set_profiling(not args.no_kernel_events)   # also zeroes the counters
+    if eng is not None:
+        assert eng.sync() == 0
+        eng.set_profiling(not args.no_kernel_events)   # also zeroes the counters
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    assert eng.sync() == 0
-    prof = eng.profile()
-    eng.set_profiling(False)
+    prof = {}
+    if eng is not None:
+        assert eng.sync() == 0
+        prof = eng.profile()
+        eng.set_profiling(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    samples_per_step = nb * L * C
-    value = world * samples_per_step * args.steps / elapsed / 1e6
+    # the job's time is the slowest rank's; its work is the sum of every rank's units
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+    total_samples = sharding.sum_over_ranks(n_eng * nb * L * C * args.steps, dev)
+    value = total_samples / elapsed / 1e6
 
     result = None
     if rank == 0:
@@ -176,7 +199,7 @@ def main():
         if not args.no_kernel_events and any(v[1] for v in prof.values()):
             dom = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[dom]
-            blocks_per_launch = args.steps * nb / launches
+            blocks_per_launch = n_eng * args.steps * nb / launches   # engine-blocks in one launch
             achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -204,12 +227,14 @@ def main():
                       if args.workload.startswith("cfg3") else "Msamples/s (output channel-samples)",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32" if s == 4 else "f64", "data": "synthetic",
             "config": {"workload": args.workload, "channels": C, "taps": taps, "partition": L,
                        "fft_size": N, "partitions": B, "blocks_per_step": nb,
-                       "blocks_per_launch": args.chunk, "engines_per_gpu": 1,
-                       "io": "interleaved frames resident in HBM", "parallelism": "replica-per-gpu"},
+                       "blocks_per_launch": args.chunk, "engines_rank0": n_eng,
+                       "streams_total": args.streams if args.streams > 0 else world,
+                       "io": "interleaved frames resident in HBM",
+                       "parallelism": "independent engines per GPU, no collective"},
             "per_gpu_value": round(value / world, 1),
             "pct_of_hbm_roofline_algorithmic": round(
                 100.0 * (value / world * 1e6) * (sum(alg.values()) / (L * C)) / (HBM_PEAK_GBS * 1e9), 2),

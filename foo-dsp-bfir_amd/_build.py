@@ -9,7 +9,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbfir_hip.so")
 SOURCES = ["kernels.hip", "engine.hip", "stage.hip"]
 HEADERS = ["kernels.h", "fft_lds.h", os.path.join("..", "..", "include", "bfir_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]
+# -ffp-contract=on: fuse only inside one source expression (the stage kernels rely on it);
+# -fno-slp-vectorize: packing the FFT butterflies into v_pk_* costs more moves than it saves
+# (the MAC kernel asks for v_pk_fma_f32 explicitly).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-slp-vectorize"]
 
 
 def _stale(target, deps):

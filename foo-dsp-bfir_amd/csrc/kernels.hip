@@ -301,6 +301,23 @@ void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s)
 // fetched once per tile instead of once per output block.
 // Explicit fma() calls pin the rounding: every instantiation (any TT) produces
 // bit-identical sums, so results do not depend on how a run is cut into chunks.
+// fp32: written on 2-wide vectors so it is v_pk_fma_f32 by construction (the
+// library is built without SLP vectorisation, which only cost the FFT kernels moves)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cmac4(float4 &ar, float4 &ai, const float4 &xr, const float4 &xi,
+                                      const float4 &hr, const float4 &hi)
+{
+    const v2f xrl = {xr.x, xr.y}, xrh = {xr.z, xr.w}, xil = {xi.x, xi.y}, xih = {xi.z, xi.w};
+    const v2f hrl = {hr.x, hr.y}, hrh = {hr.z, hr.w}, hil = {hi.x, hi.y}, hih = {hi.z, hi.w};
+    v2f arl = {ar.x, ar.y}, arh = {ar.z, ar.w}, ail = {ai.x, ai.y}, aih = {ai.z, ai.w};
+    arl = __builtin_elementwise_fma(xrl, hrl, arl); arl = __builtin_elementwise_fma(-xil, hil, arl);
+    arh = __builtin_elementwise_fma(xrh, hrh, arh); arh = __builtin_elementwise_fma(-xih, hih, arh);
+    ail = __builtin_elementwise_fma(xrl, hil, ail); ail = __builtin_elementwise_fma(xil, hrl, ail);
+    aih = __builtin_elementwise_fma(xrh, hih, aih); aih = __builtin_elementwise_fma(xih, hrh, aih);
+    ar.x = arl.x; ar.y = arl.y; ar.z = arh.x; ar.w = arh.y;
+    ai.x = ail.x; ai.y = ail.y; ai.z = aih.x; ai.w = aih.y;
+}
+
 template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, const V4 &xr, const V4 &xi,
                                                              const V4 &hr, const V4 &hi)
 {
@@ -444,117 +461,142 @@ void launch_mac(const MacArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // a5 / a13: staging between interleaved raw frames and planar time buffers
 // ---------------------------------------------------------------------------
-// Both directions move one tile of STAGE_TILE frames x C channels per step
-// through LDS, so the interleaved side is touched with contiguous (16-byte when
-// aligned) accesses and the planar side with lane-consecutive ones, whatever C
-// and the sample widths are.
-constexpr int STAGE_TILE = 256;
+// One thread moves one whole frame (C samples, at most 64 bytes): the
+// interleaved side is touched with the widest word the frame size and the
+// buffer alignment allow (16 bytes for 8 x float32), so a wave covers a
+// contiguous 2 KiB there, and the planar side lane-consecutively.  No LDS, no
+// barrier: every thread is independent and keeps its loads in flight.
+constexpr int STAGE_THREADS = 256;
 
-template <typename W> __device__ __forceinline__ void tile_copy(W *dst, const W *src, int n, int tid)
+template <int WB> struct StageWord;
+template <> struct StageWord<4>  { using type = unsigned int; };
+template <> struct StageWord<8>  { using type = uint2; };
+template <> struct StageWord<16> { using type = uint4; };
+
+__device__ __forceinline__ void words_from(unsigned int *w, unsigned int q) { w[0] = q; }
+__device__ __forceinline__ void words_from(unsigned int *w, uint2 q) { w[0] = q.x; w[1] = q.y; }
+__device__ __forceinline__ void words_from(unsigned int *w, uint4 q) { w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
+__device__ __forceinline__ void words_to(const unsigned int *w, unsigned int &q) { q = w[0]; }
+__device__ __forceinline__ void words_to(const unsigned int *w, uint2 &q) { q.x = w[0]; q.y = w[1]; }
+__device__ __forceinline__ void words_to(const unsigned int *w, uint4 &q) { q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3]; }
+
+template <typename TR> __device__ __forceinline__ TR sample_from_words(const unsigned int *w, int c);
+template <> __device__ __forceinline__ float sample_from_words<float>(const unsigned int *w, int c) { return __uint_as_float(w[c]); }
+template <> __device__ __forceinline__ double sample_from_words<double>(const unsigned int *w, int c)
 {
-    for (int i = tid; i < n; i += STAGE_TILE) dst[i] = src[i];
+    return __hiloint2double((int)w[2 * c + 1], (int)w[2 * c]);
+}
+__device__ __forceinline__ void sample_to_words(unsigned int *w, int c, float v) { w[c] = __float_as_uint(v); }
+__device__ __forceinline__ void sample_to_words(unsigned int *w, int c, double v)
+{
+    w[2 * c] = (unsigned int)__double2loint(v); w[2 * c + 1] = (unsigned int)__double2hiint(v);
 }
 
-// contiguous global <-> LDS copy of `bytes` bytes (multiple of 4)
-__device__ __forceinline__ void tile_load(void *lds, const void *g, int bytes, int tid)
+// Largest word (16 / 8 / 4 bytes) that divides the frame and every address the kernel forms.
+static int stage_word_bytes(const void *raw, long eng_stride_bytes, long frame_off, int C, int spacing, int raw_bytes)
 {
-    if ((((size_t)g) & 15) == 0 && (bytes & 15) == 0) tile_copy((uint4 *)lds, (const uint4 *)g, bytes >> 4, tid);
-    else tile_copy((unsigned int *)lds, (const unsigned int *)g, bytes >> 2, tid);
-}
-__device__ __forceinline__ void tile_store(void *g, const void *lds, int bytes, int tid)
-{
-    if ((((size_t)g) & 15) == 0 && (bytes & 15) == 0) tile_copy((uint4 *)g, (const uint4 *)lds, bytes >> 4, tid);
-    else tile_copy((unsigned int *)g, (const unsigned int *)lds, bytes >> 2, tid);
+    if (spacing != C) return 4;   // a channel subset of a wider frame (stage API): sample by sample
+    const long fb = (long)C * raw_bytes;
+    const size_t base = (size_t)raw + (size_t)(frame_off * fb);
+    for (int wb = 16; wb > 4; wb >>= 1)
+        if (fb % wb == 0 && base % wb == 0 && eng_stride_bytes % wb == 0) return wb;
+    return 4;
 }
 
-template <typename TR, typename T> __global__ __launch_bounds__(STAGE_TILE) void k_stage_in(StageInArgs a)
+template <typename TR, typename T, int WB> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_in(StageInArgs a)
 {
-    __shared__ __attribute__((aligned(16))) TR tile[STAGE_TILE * BFIR_MAXCH];
-    const int tid = threadIdx.x, e = blockIdx.y, C = a.C;
-    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
-    const TR *__restrict__ raw = (const TR *)((const char *)a.raw + (long)e * a.eng_stride_bytes) + a.frame_off * a.spacing;
+    using W = typename StageWord<WB>::type;
+    constexpr int WW = WB / 4;                       // 32-bit words per load
+    const int C = a.C, e = blockIdx.y;
+    const int fw = C * (int)sizeof(TR) / 4;          // 32-bit words per frame, <= 16
+    const char *__restrict__ raw = (const char *)a.raw + (long)e * a.eng_stride_bytes +
+                                   a.frame_off * a.spacing * (long)sizeof(TR);
     T *__restrict__ dst = (T *)a.dst + (long)e * C * a.dst_ch_stride + a.dst_off;
-    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const long f0 = tl * STAGE_TILE;
-        const int nf = (int)((a.n_frames - f0) < STAGE_TILE ? (a.n_frames - f0) : STAGE_TILE);
-        if (a.spacing == C) {
-            tile_load(tile, raw + f0 * C, nf * C * (int)sizeof(TR), tid);
-        } else {  // channels are a subset of a wider frame (stage API): strided gather
-            for (int i = tid; i < nf * C; i += STAGE_TILE) tile[i] = raw[(f0 + i / C) * a.spacing + i % C];
-        }
-        __syncthreads();
-        if (tid < nf)
-            for (int c = 0; c < C; c++) dst[(long)c * a.dst_ch_stride + f0 + tid] = (T)tile[tid * C + c];
-        __syncthreads();
+    const long step = (long)gridDim.x * STAGE_THREADS;
+    for (long f = (long)blockIdx.x * STAGE_THREADS + threadIdx.x; f < a.n_frames; f += step) {
+        unsigned int w[16];
+        const W *p = (const W *)(raw + f * a.spacing * (long)sizeof(TR));
+#pragma unroll
+        for (int i = 0; i < 16 / WW; i++)
+            if (i * WW < fw) words_from(w + i * WW, p[i]);
+#pragma unroll
+        for (int c = 0; c < BFIR_MAXCH; c++)
+            if (c < C) dst[(long)c * a.dst_ch_stride + f] = (T)sample_from_words<TR>(w, c);
     }
+}
+
+template <typename TR, typename T> static void launch_stage_in_t(const StageInArgs &a, dim3 grid, int wb, hipStream_t s)
+{
+    dim3 block(STAGE_THREADS);
+    if (wb == 16) hipLaunchKernelGGL((k_stage_in<TR, T, 16>), grid, block, 0, s, a);
+    else if (wb == 8) hipLaunchKernelGGL((k_stage_in<TR, T, 8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_stage_in<TR, T, 4>), grid, block, 0, s, a);
 }
 
 void launch_stage_in(const StageInArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
-    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
-    dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), a.n_eng), block(STAGE_TILE);
-    if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_in<float, float>), grid, block, 0, s, a);
-    else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_in<float, double>), grid, block, 0, s, a);
-    else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_in<double, float>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_stage_in<double, double>), grid, block, 0, s, a);
+    const long nblk = (a.n_frames + STAGE_THREADS - 1) / STAGE_THREADS;
+    dim3 grid((unsigned)(nblk < 2048 ? nblk : 2048), a.n_eng);
+    const int wb = stage_word_bytes(a.raw, a.eng_stride_bytes, a.frame_off, a.C, a.spacing, a.raw_bytes);
+    if (a.raw_bytes == 4 && a.realsize == 4) launch_stage_in_t<float, float>(a, grid, wb, s);
+    else if (a.raw_bytes == 4) launch_stage_in_t<float, double>(a, grid, wb, s);
+    else if (a.realsize == 4) launch_stage_in_t<double, float>(a, grid, wb, s);
+    else launch_stage_in_t<double, double>(a, grid, wb, s);
 }
 
-__device__ __forceinline__ unsigned long long abs_bits(float v) { return (unsigned long long)__float_as_uint(fabsf(v)); }
+// |v| as an integer whose ordering equals the ordering of the magnitudes
+__device__ __forceinline__ unsigned int abs_bits(float v) { return __float_as_uint(fabsf(v)); }
 __device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
-template <typename T, typename TR> __global__ __launch_bounds__(STAGE_TILE) void k_stage_out(StageOutArgs a)
+template <typename T, typename TR, int WB> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_out(StageOutArgs a)
 {
-    __shared__ __attribute__((aligned(16))) TR tile[STAGE_TILE * BFIR_MAXCH];
-    __shared__ unsigned long long red_max[STAGE_TILE / 64][BFIR_MAXCH];
-    __shared__ unsigned int red_cnt[STAGE_TILE / 64][BFIR_MAXCH];
+    using W = typename StageWord<WB>::type;
+    using Bits = decltype(abs_bits((T)0));
+    constexpr int WW = WB / 4;
+    __shared__ Bits red_max[STAGE_THREADS / 64][BFIR_MAXCH];
+    __shared__ unsigned int red_cnt[STAGE_THREADS / 64][BFIR_MAXCH];
     const int tid = threadIdx.x, e = blockIdx.y, C = a.C;
-    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
+    const int fw = C * (int)sizeof(TR) / 4;
     const T rmax = (T)a.max, rmin = (T)(-a.max);
-    TR *__restrict__ raw = (TR *)((char *)a.raw + (long)e * a.eng_stride_bytes) + a.frame_off * a.spacing;
+    char *__restrict__ raw = (char *)a.raw + (long)e * a.eng_stride_bytes + a.frame_off * a.spacing * (long)sizeof(TR);
     const T *__restrict__ src = (const T *)a.src + (long)e * C * a.src_ch_stride;
-    unsigned long long mx[BFIR_MAXCH];
+    Bits mx[BFIR_MAXCH];
     unsigned int cnt[BFIR_MAXCH];
 #pragma unroll
-    for (int c = 0; c < BFIR_MAXCH; c++) { mx[c] = 0ull; cnt[c] = 0u; }
-    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const long f0 = tl * STAGE_TILE;
-        const int nf = (int)((a.n_frames - f0) < STAGE_TILE ? (a.n_frames - f0) : STAGE_TILE);
-        if (tid < nf) {
-            const long f = f0 + tid;
-            const bool first_of_block = (f % a.L) == 0;
+    for (int c = 0; c < BFIR_MAXCH; c++) { mx[c] = 0; cnt[c] = 0u; }
+    const long step = (long)gridDim.x * STAGE_THREADS;
+    for (long f = (long)blockIdx.x * STAGE_THREADS + tid; f < a.n_frames; f += step) {
+        unsigned int w[16];
+        const bool first_of_block = (f % a.L) == 0;
 #pragma unroll
-            for (int c = 0; c < BFIR_MAXCH; c++) {
-                if (c < C) {
-                    const T v = src[(long)c * a.src_ch_stride + f];
-                    tile[tid * C + c] = (TR)v;
-                    // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
-                    cnt[c] += ((v < (T)0) ? (v < rmin) : (v > rmax)) ? 1u : 0u;
-                    const unsigned long long bits = (v == v) ? abs_bits(v) : 0ull;
-                    mx[c] = bits > mx[c] ? bits : mx[c];
-                    // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-                    if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
-                }
+        for (int c = 0; c < BFIR_MAXCH; c++) {
+            if (c < C) {
+                const T v = src[(long)c * a.src_ch_stride + f];
+                sample_to_words(w, c, (TR)v);
+                // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+                cnt[c] += ((v < (T)0) ? (v < rmin) : (v > rmax)) ? 1u : 0u;
+                const Bits bits = (v == v) ? abs_bits(v) : (Bits)0;
+                mx[c] = bits > mx[c] ? bits : mx[c];
+                // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+                if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
             }
         }
-        __syncthreads();
-        if (a.spacing == C) {
-            tile_store(raw + f0 * C, tile, nf * C * (int)sizeof(TR), tid);
-        } else {
-            for (int i = tid; i < nf * C; i += STAGE_TILE) raw[(f0 + i / C) * a.spacing + i % C] = tile[i];
-        }
-        __syncthreads();
+        W *p = (W *)(raw + f * a.spacing * (long)sizeof(TR));
+#pragma unroll
+        for (int i = 0; i < 16 / WW; i++)
+            if (i * WW < fw) { W q; words_to(w + i * WW, q); p[i] = q; }
     }
     // one filtered atomic per block and channel: the peak only ever grows, so a
     // stale read of it can cost an extra atomic but never a wrong result
 #pragma unroll
     for (int c = 0; c < BFIR_MAXCH; c++) {
         if (c < C) {
-            unsigned long long m = mx[c];
+            Bits m = mx[c];
             unsigned int n = cnt[c];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long om = __shfl_xor(m, o);
+                const Bits om = __shfl_xor(m, o);
                 m = om > m ? om : m;
                 n += __shfl_xor(n, o);
             }
@@ -563,24 +605,35 @@ template <typename T, typename TR> __global__ __launch_bounds__(STAGE_TILE) void
     }
     __syncthreads();
     if (tid < C) {
-        unsigned long long m = 0ull;
+        Bits m = 0;
         unsigned int n = 0u;
-        for (int w = 0; w < STAGE_TILE / 64; w++) { m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; }
+        for (int w = 0; w < STAGE_THREADS / 64; w++) { m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; }
         DevOverflow *of = a.overflow + (e * C + tid);
         if (n) atomicAdd(&of->n_overflows, n);
-        if (m > *(volatile unsigned long long *)&of->largest_bits) atomicMax(&of->largest_bits, m);
+        if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
+            atomicMax(&of->largest_bits, (unsigned long long)m);
     }
+}
+
+template <typename T, typename TR> static void launch_stage_out_t(const StageOutArgs &a, dim3 grid, int wb, hipStream_t s)
+{
+    dim3 block(STAGE_THREADS);
+    if (wb == 16) hipLaunchKernelGGL((k_stage_out<T, TR, 16>), grid, block, 0, s, a);
+    else if (wb == 8) hipLaunchKernelGGL((k_stage_out<T, TR, 8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_stage_out<T, TR, 4>), grid, block, 0, s, a);
 }
 
 void launch_stage_out(const StageOutArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
-    const long ntiles = (a.n_frames + STAGE_TILE - 1) / STAGE_TILE;
-    dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), a.n_eng), block(STAGE_TILE);
-    if (a.raw_bytes == 4 && a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, float>), grid, block, 0, s, a);
-    else if (a.raw_bytes == 4) hipLaunchKernelGGL((k_stage_out<double, float>), grid, block, 0, s, a);
-    else if (a.realsize == 4) hipLaunchKernelGGL((k_stage_out<float, double>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_stage_out<double, double>), grid, block, 0, s, a);
+    // a few frames per thread so the per-block reduction is amortised
+    const long nblk = (a.n_frames + 4 * STAGE_THREADS - 1) / (4 * STAGE_THREADS);
+    dim3 grid((unsigned)(nblk < 2048 ? (nblk > 0 ? nblk : 1) : 2048), a.n_eng);
+    const int wb = stage_word_bytes(a.raw, a.eng_stride_bytes, a.frame_off, a.C, a.spacing, a.raw_bytes);
+    if (a.raw_bytes == 4 && a.realsize == 4) launch_stage_out_t<float, float>(a, grid, wb, s);
+    else if (a.raw_bytes == 4) launch_stage_out_t<double, float>(a, grid, wb, s);
+    else if (a.realsize == 4) launch_stage_out_t<float, double>(a, grid, wb, s);
+    else launch_stage_out_t<double, double>(a, grid, wb, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -327,48 +327,19 @@ template <typename V4> __device__ __forceinline__ void cmac4(V4 &ar, V4 &ai, con
     ar.w = fma(xr.w, hr.w, ar.w); ar.w = fma(-xi.w, hi.w, ar.w); ai.w = fma(xr.w, hi.w, ai.w); ai.w = fma(xi.w, hr.w, ai.w);
 }
 
-template <typename T, int TT, int WPE, int D>
-__global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, int G)
+// The partition loop of one thread.  Partitions in the reference's order
+// i = 0 .. nb-1, TT per trip so the rotating window keeps compile-time register
+// names.  Operands are fetched D steps ahead into a small register queue: step i
+// consumes H_i and the one new delay-line spectrum X[t0-i] (entering the window
+// in place of the entry nobody needs any more) from queue slot i mod D, refills
+// that slot with the operands of step i+D, then does its TT x 4 complex MACs, so
+// D steps of arithmetic cover the load latency.  DCNY: also carry the two real
+// sums of group 0 (DC, Nyquist); only the wave owning group 0 runs that version.
+template <typename T, int TT, int D, bool DCNY, typename V4>
+__device__ __forceinline__ void mac_partitions(V4 (&accr)[TT], V4 (&acci)[TT], T (&dc)[TT], T (&ny)[TT],
+                                               V4 (&wr)[TT], V4 (&wi)[TT], const V4 *__restrict__ X,
+                                               const V4 *__restrict__ H, int nb, int ring, int sl, long slot4)
 {
-    static_assert(D >= 1 && TT % D == 0, "prefetch depth must divide the time tile");
-    using V4 = typename Vec4<T>::type;
-    // XCD-aware, bijective block -> work remap: each XCD (blocks b, b+8, ...)
-    // gets one contiguous range of work items, ordered (channel, bin tile)
-    // major / time tile minor, so its L2 holds a slice of H for the whole
-    // launch while consecutive time tiles re-use each other's spectra.
-    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
-    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
-    const int s = w / nTT, tt = w - s * nTT;
-    const int gc = s / nbt, bt = s - gc * nbt;
-    const int g = bt * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const int t0 = tt * TT;
-    const long slot4 = a.N / 4;  // V4 elements per spectrum
-    const V4 *__restrict__ X = (const V4 *)((const T *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
-    const V4 *__restrict__ H = (const V4 *)((const T *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
-    const int nb = a.nblk[gc];
-    const int ring = a.ring;
-    // DC and Nyquist share group 0 as two independent reals; only the wave
-    // that owns group 0 carries the two extra sums
-    const bool wave0 = (bt == 0) && (threadIdx.x < 64);
-
-    V4 accr[TT], acci[TT], wr[TT], wi[TT];
-    T dc[TT], ny[TT];
-    int sl = (a.base_slot + t0) % ring;  // delay-line slot of block t0
-#pragma unroll
-    for (int j = 0; j < TT; j++) {
-        accr[j] = V4{0, 0, 0, 0}; acci[j] = V4{0, 0, 0, 0};
-        dc[j] = (T)0; ny[j] = (T)0;
-        int sj = sl + j; if (sj >= ring) sj -= ring;
-        wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
-    }
-    // Partitions in the reference's order i = 0 .. nb-1, TT per trip so the
-    // rotating window keeps compile-time register names.  Operands are fetched
-    // D steps ahead into a small register queue: step i consumes H_i and the
-    // one new delay-line spectrum X[t0-i] (entering the window in place of the
-    // entry nobody needs any more) from queue slot i mod D, refills that slot
-    // with the operands of step i+D, then does its TT x 4 complex MACs, so D
-    // steps of arithmetic cover the load latency.
     V4 qhr[D], qhi[D], qxr[D], qxi[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -394,7 +365,7 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
                 for (int j = 0; j < TT; j++) {
                     const int idx = (j - ii + TTc) % TTc;  // window slot holding X[t0 + j - i]
                     cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
-                    if (wave0) {
+                    if constexpr (DCNY) {
                         dc[j] = fma(wr[idx].x, hr.x, dc[j]);
                         ny[j] = fma(wi[idx].x, hi.x, ny[j]);
                     }
@@ -402,6 +373,45 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
             }
         }
     }
+}
+
+template <typename T, int TT, int WPE, int D>
+__global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, int G)
+{
+    static_assert(D >= 1 && TT % D == 0, "prefetch depth must divide the time tile");
+    using V4 = typename Vec4<T>::type;
+    // XCD-aware, bijective block -> work remap: each XCD (blocks b, b+8, ...)
+    // gets one contiguous range of work items, ordered (channel, bin tile)
+    // major / time tile minor, so its L2 holds a slice of H for the whole
+    // launch while consecutive time tiles re-use each other's spectra.
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTT, tt = w - s * nTT;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int g = bt * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int t0 = tt * TT;
+    const long slot4 = a.N / 4;  // V4 elements per spectrum
+    const V4 *__restrict__ X = (const V4 *)((const T *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
+    const V4 *__restrict__ H = (const V4 *)((const T *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+    // DC and Nyquist share group 0 as two independent reals; only the wave that
+    // owns group 0 carries the two extra sums (a scalar, wave-uniform branch)
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)((bt == 0) && (threadIdx.x < 64))) != 0;
+
+    V4 accr[TT], acci[TT], wr[TT], wi[TT];
+    T dc[TT], ny[TT];
+    const int sl = (a.base_slot + t0) % ring;  // delay-line slot of block t0
+#pragma unroll
+    for (int j = 0; j < TT; j++) {
+        accr[j] = V4{0, 0, 0, 0}; acci[j] = V4{0, 0, 0, 0};
+        dc[j] = (T)0; ny[j] = (T)0;
+        int sj = sl + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
+    }
+    if (wave0) mac_partitions<T, TT, D, true>(accr, acci, dc, ny, wr, wi, X, H, nb, ring, sl, slot4);
+    else mac_partitions<T, TT, D, false>(accr, acci, dc, ny, wr, wi, X, H, nb, ring, sl, slot4);
     T *__restrict__ Y = (T *)a.y + (long)gc * a.y_ch_stride;
 #pragma unroll
     for (int j = 0; j < TT; j++) {
@@ -452,7 +462,7 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         else if (tt >= 2) launch_mac_t<float, 2, 4, 1>(a, s);
         else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
-        if (tt >= 4) launch_mac_t<double, 4, 2, 1>(a, s);
+        if (tt >= 4) launch_mac_t<double, 4, 1, 1>(a, s);   // 1 wave/SIMD: the 2-wave build spills to scratch
         else if (tt >= 2) launch_mac_t<double, 2, 3, 1>(a, s);
         else launch_mac_t<double, 1, 4, 1>(a, s);
     }

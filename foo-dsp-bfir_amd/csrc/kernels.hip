@@ -301,8 +301,11 @@ void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s)
 // fetched once per tile instead of once per output block.
 // Explicit fma() calls pin the rounding: every instantiation (any TT) produces
 // bit-identical sums, so results do not depend on how a run is cut into chunks.
-// fp32: written on 2-wide vectors so it is v_pk_fma_f32 by construction (the
-// library is built without SLP vectorisation, which only cost the FFT kernels moves)
+// fp32: written on 2-wide vectors so it is v_pk_fma_f32 by construction (the library
+// is built without SLP vectorisation).  Measured on MI355X (scripts/ubench/valu_rate.hip,
+// profiles/r01_valu_rate.txt): a wave64 v_fma_f32 issues every ~4 cycles per SIMD
+// (59-75 TFLOP/s chip-wide for 1-8 waves/SIMD), a v_pk_fma_f32 every ~7 (71-90 TFLOP/s),
+// so the packed form is worth 15-20 % here.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cmac4(float4 &ar, float4 &ai, const float4 &xr, const float4 &xi,
                                       const float4 &hr, const float4 &hi)
@@ -424,6 +427,142 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_mac_lds: the same sums with the operands shared through LDS (fp32)
+// ---------------------------------------------------------------------------
+// A workgroup of 4 waves owns 64 groups (256 bins) of one channel for 32
+// consecutive output blocks: wave w computes blocks tb+8w .. tb+8w+7 with the
+// same rotating register window as k_mac.  Per partition step the workgroup
+// needs H_i (shared by all four waves) and, per wave, one new delay-line
+// spectrum X[tb+8w-i] -- which is exactly what wave w-1 fetched 8 steps
+// earlier.  So the spectra live in a 32-entry LDS ring: only X[tb-i] and H_i
+// are fetched from memory each step (4 KiB per workgroup-step instead of
+// 16 KiB), one 16-byte load per lane, issued D steps ahead; everything else is
+// ds_read_b128 of lane-contiguous data (conflict free).  One barrier per step.
+// Sums are formed in the same order with the same fma chain as k_mac, so the
+// two kernels give bit-identical results.
+template <int D, bool DCNY>
+__device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[8], float (&dc)[8], float (&ny)[8],
+                                              float4 (&wr)[8], float4 (&wi)[8], float4 (*s_ring)[2][64],
+                                              float4 (*s_h)[2][64], const float4 *__restrict__ duty_base,
+                                              long duty_slot4, bool duty_is_h, int duty_plane, int nb, int ring,
+                                              int sl_tb, int lane, int wv)
+{
+    // duty: this wave fetches one plane (re or im) of H_s (waves 0,1) or of
+    // X[tb - s] (waves 2,3) for every step s, D steps ahead of its use
+    // (a native vector type: HIP's float4 struct would be copied through private memory)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f q[D];
+    const v4f *__restrict__ dbase = (const v4f *)duty_base;
+    // The duty operand of step s sits at slot index dnext when s is the next one to fetch:
+    // H waves walk up (clamped to the last partition), X waves walk down the ring with wrap.
+    int dnext = duty_is_h ? 0 : sl_tb;
+#define BFIR_DUTY_ADVANCE()                                                                         \
+    do {                                                                                            \
+        if (duty_is_h) { if (dnext < nb - 1) dnext += 1; }                                          \
+        else { dnext -= 1; if (dnext < 0) dnext += ring; }                                          \
+    } while (0)
+#define BFIR_DUTY_LOAD() dbase[dnext * duty_slot4 + duty_plane]
+#define BFIR_DUTY_STORE(s_, v_)                                                                     \
+    do {                                                                                            \
+        float4 *dst_ = duty_is_h ? &s_h[(s_) & 1][duty_plane][lane] : &s_ring[(-(s_)) & 31][duty_plane][lane]; \
+        *(v4f *)dst_ = (v_);                                                                        \
+    } while (0)
+    // step 0: H_0 straight to LDS (X waves have no duty: the windows are loaded already)
+    if (duty_is_h) { const v4f h0 = BFIR_DUTY_LOAD(); BFIR_DUTY_STORE(0, h0); }
+#pragma unroll
+    for (int d = 0; d < D; d++) { BFIR_DUTY_ADVANCE(); q[(1 + d) % D] = BFIR_DUTY_LOAD(); }   // steps 1 .. D
+    __syncthreads();
+    for (int i0 = 0; i0 < nb; i0 += 8) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            const int i = i0 + ii;
+            if (i < nb) {   // uniform over the workgroup
+                const float4 hr = s_h[ii & 1][0][lane], hi = s_h[ii & 1][1][lane];
+                if (i > 0) {
+                    const int e = (8 * wv - i) & 31;             // ring entry holding X[tb + 8 wv - i]
+                    wr[(8 - ii) % 8] = s_ring[e][0][lane]; wi[(8 - ii) % 8] = s_ring[e][1][lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int idx = (j - ii + 8) % 8;            // window slot holding X[t0 + j - i]
+                    cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                    if constexpr (DCNY) {
+                        dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                        ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                    }
+                }
+                // publish the operands of step i+1, refill the queue slot with those of step i+1+D
+                BFIR_DUTY_STORE(i + 1, q[(ii + 1) % D]);
+                BFIR_DUTY_ADVANCE();
+                q[(ii + 1) % D] = BFIR_DUTY_LOAD();
+                __syncthreads();
+            }
+        }
+    }
+#undef BFIR_DUTY_ADVANCE
+#undef BFIR_DUTY_LOAD
+#undef BFIR_DUTY_STORE
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
+{
+    __shared__ __attribute__((aligned(16))) float4 s_ring[32][2][64];
+    __shared__ __attribute__((aligned(16))) float4 s_h[2][2][64];
+    static_assert(8 % D == 0, "prefetch depth must divide the unroll");
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTQ, tq = w - s * nTQ;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = bt * 64 + lane;
+    const int tb = tq * 32, t0 = tb + 8 * wv;
+    const long slot4 = a.N / 4;
+    const float4 *__restrict__ X = (const float4 *)((const float *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
+    const float4 *__restrict__ H = (const float4 *)((const float *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+    const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
+
+    float4 accr[8], acci[8], wr[8], wi[8];
+    float dc[8], ny[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        accr[j] = float4{0, 0, 0, 0}; acci[j] = float4{0, 0, 0, 0};
+        dc[j] = 0.f; ny[j] = 0.f;
+        int sj = sl_tb + 8 * wv + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
+        s_ring[8 * wv + j][0][lane] = wr[j]; s_ring[8 * wv + j][1][lane] = wi[j];
+    }
+    const bool duty_is_h = wv < 2;
+    const int plane = wv & 1;
+    if (bt == 0)
+        mac_lds_steps<D, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
+                               nb, ring, sl_tb, lane, wv);
+    else
+        mac_lds_steps<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
+                                nb, ring, sl_tb, lane, wv);
+    float *__restrict__ Y = (float *)a.y + (long)gc * a.y_ch_stride;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) {
+            if (g == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            float4 *yo = (float4 *)(Y + (long)t * a.N) + 2 * g;
+            yo[0] = accr[j]; yo[1] = acci[j];
+        }
+    }
+}
+
+template <int D> static void launch_mac_lds(const MacArgs &a, hipStream_t s)
+{
+    const int nbt = a.N / 8 / 64;              // bin tiles of 64 groups
+    const int nTQ = (a.n_t + 31) / 32;         // time tiles of 32 blocks
+    hipLaunchKernelGGL((k_mac_lds<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+}
+
 template <typename T, int TT, int WPE, int D> static void launch_mac_t(const MacArgs &a, hipStream_t s)
 {
     const int G = a.N / 8;
@@ -453,7 +592,11 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     const int tt = a.n_t;
     if (a.realsize == 4) {
         const int v = mac_variant();
-        if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);
+        const bool lds_ok = a.N >= 512 && tt >= 32;   // 64-group tiles, 32-block time tiles
+        if (lds_ok && v == 0) launch_mac_lds<8>(a, s);
+        else if (lds_ok && v == 6) launch_mac_lds<4>(a, s);
+        else if (lds_ok && v == 7) launch_mac_lds<2>(a, s);
+        else if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);
         else if (tt >= 16 && v == 3) launch_mac_t<float, 16, 1, 4>(a, s);
         else if (tt >= 8 && v == 1) launch_mac_t<float, 8, 2, 1>(a, s);
         else if (tt >= 4 && v == 4) launch_mac_t<float, 4, 3, 2>(a, s);

@@ -10,12 +10,12 @@ from ._lib import BfirError, BufferFormat, Overflow
 
 
 def make_buffer_format(fmt, channel, n_channels):
-    """setup_input / setup_output for a float format (brutefir/brutefir.cpp:512-582)."""
-    nbytes = {_lib.SAMPLE_FORMAT_FLOAT_LE: 4, _lib.SAMPLE_FORMAT_FLOAT64_LE: 8}[fmt]
+    """setup_input / setup_output for any sample format (brutefir/brutefir.cpp:435-582)."""
+    nbytes = {1: 1, 2: 2, 3: 2, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 8, 11: 8}[fmt]
     bf = BufferFormat()
-    bf.sf.isfloat, bf.sf.swap = True, False
+    bf.sf.isfloat, bf.sf.swap = fmt >= 8, fmt in (3, 5, 7, 9, 11)
     bf.sf.bytes = bf.sf.sbytes = nbytes
-    bf.sf.scale, bf.sf.format = 1.0, fmt
+    bf.sf.scale, bf.sf.format = 1.0, fmt      # the stage calls take their scales explicitly
     bf.sample_spacing, bf.byte_offset = n_channels, channel * nbytes
     return bf
 

@@ -79,13 +79,8 @@ extern "C" const char *bfir_version(void) { return "bfir-hip 0.1 (gfx950)"; }
         }                                                                          \
     } while (0)
 
-static int fmt_bytes(int fmt)
-{
-    // brutefir/brutefir.cpp:512-538 (FLOAT_LE, FLOAT64_LE: scale 1.0, no swap)
-    if (fmt == BFIR_SAMPLE_FORMAT_FLOAT_LE) return 4;
-    if (fmt == BFIR_SAMPLE_FORMAT_FLOAT64_LE) return 8;
-    return 0;
-}
+// brutefir::setup_sample_format (brutefir/brutefir.cpp:435-538): all eleven formats
+static int fmt_bytes(int fmt) { return fmt_info(fmt).bytes; }
 
 // A block of planar time samples somewhere in HBM: [GC][L] with a channel stride.
 struct BlockRef {
@@ -96,7 +91,7 @@ struct BlockRef {
 struct bfir_engine {
     int device = 0;
     int L = 0, N = 0, B = 0, s = 0, C = 0, n_eng = 1, GC = 0;
-    int in_bytes = 0, out_bytes = 0;
+    int in_bytes = 0, out_bytes = 0, in_fmt = 0, out_fmt = 0;
     double in_scale = 1.0, out_scale = 1.0, of_max = 1.0;
     FftPlan plan;
     int chunk = 0, ring = 0;        // allocated geometry
@@ -220,7 +215,11 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         bfir_logf("Invalid length %d.", filter_length); *err = BFIR_ERR_ARG; return nullptr;
     }
     if (filter_blocks < 1 || n_engines < 1) { *err = BFIR_ERR_ARG; return nullptr; }
-    if (!fmt_bytes(in_format) || !fmt_bytes(out_format) || apply_dither) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
+    if (!fmt_bytes(in_format) || !fmt_bytes(out_format)) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
+    // Dither only ever acts on integer outputs (fftw_convolver.cpp:421).  The reference's own
+    // dither path cannot run: dither_preloop_real2int_hp_tpdf is empty (dither.cpp:190-194), so
+    // dither_state_t.randtab stays NULL and real2int_hp_tpdf dereferences it.  Refused, not emulated.
+    if (apply_dither && !fmt_info(out_format).isfloat) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
     int ndev = bfir_device_count();
     if (ndev <= 0) { *err = BFIR_ERR_NO_DEVICE; return nullptr; }
     if (device < 0 || device >= ndev) { *err = BFIR_ERR_ARG; return nullptr; }
@@ -231,6 +230,12 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     e->L = filter_length; e->N = 2 * filter_length; e->B = filter_blocks; e->s = realsize;
     e->C = channels; e->n_eng = n_engines; e->GC = n_engines * channels;
     e->in_bytes = fmt_bytes(in_format); e->out_bytes = fmt_bytes(out_format);
+    e->in_fmt = in_format; e->out_fmt = out_format;
+    // setup_input: normalised scale 1/2^(bits-1); setup_output: full scale; overflow max
+    // 2^(bits-1)-1 for integers, 1.0 for floats (brutefir.cpp:395-420, 546-582, 672-684)
+    e->in_scale = fmt_info(in_format).isfloat ? 1.0 : 1.0 / fmt_full_scale(in_format);
+    e->out_scale = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format);
+    e->of_max = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format) - 1.0;
     e->nblk.assign(e->GC, 0);
     e->eng_init.assign(n_engines, 0);
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
@@ -473,7 +478,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         ProfScope ps(e, BFIR_K_STAGE_IN, sf);
         StageInArgs a;
         a.raw = d_in; a.eng_stride_bytes = in_stride; a.frame_off = frame_off;
-        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->in_bytes; a.spacing = e->C;
+        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->in_bytes; a.spacing = e->C; a.fmt = e->in_fmt;
         a.n_frames = (long)tc * e->L;
         a.dst = tin; a.dst_ch_stride = t_stride; a.dst_off = 0;
         a.realsize = e->s;
@@ -521,7 +526,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         ProfScope ps(e, BFIR_K_STAGE_OUT, st);
         StageOutArgs a;
         a.raw = d_out; a.eng_stride_bytes = out_stride; a.frame_off = frame_off;
-        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->out_bytes; a.spacing = e->C;
+        a.n_eng = e->n_eng; a.C = e->C; a.raw_bytes = e->out_bytes; a.spacing = e->C; a.fmt = e->out_fmt;
         a.n_frames = (long)tc * e->L;
         a.src = e->tout; a.src_ch_stride = t_stride;
         a.realsize = e->s; a.L = e->L; a.max = e->of_max;
@@ -678,7 +683,7 @@ extern "C" int bfir_engine_get_overflow(bfir_engine *e, int channel, bfir_overfl
     DevOverflow d;
     HIP_TRY(hipMemcpy(&d, e->d_of + channel, sizeof(d), hipMemcpyDeviceToHost));
     of->n_overflows = d.n_overflows;
-    of->intlargest = 0;
+    of->intlargest = d.intlargest;
     if (e->s == 4) {
         unsigned int u = (unsigned int)d.largest_bits;
         float f;

@@ -16,10 +16,14 @@
 // reversal).  Twiddles come from a per-plan table built on the host in
 // double precision (see FftPlanHost in kernels.hip): tw[off(s) + (r-1) p + k].
 //
-// LDS layout: logical index i is stored at i ^ ((i >> 4) & 15).  With 8-byte
-// (float2) or 16-byte (double2) elements this makes the stride-R writes of
-// the first pass, the 16-runs of the second and every unit-stride read
-// conflict-free on gfx950's 64-bank LDS.
+// LDS layout: logical index i is stored at i + (i >> 5) (one pad element per
+// 32).  With 8-byte (float2) or 16-byte (double2) elements every access of the
+// passes is conflict-free on gfx950's 64-bank LDS except the stride-R writes
+// of the first pass (2-way), and every address is a per-thread base plus a
+// compile-time offset.  (An XOR swizzle i ^ ((i >> 4) & 15) is conflict-free
+// everywhere but costs a VALU address computation per element; on a kernel
+// that is bound by VALU issue -- 4 cycles per wave64 instruction, see
+// profiles/r01_valu_rate.txt -- the padding is faster.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -87,9 +91,15 @@ __device__ __forceinline__ void mul_w16(T &re, T &im)
     }
 }
 
+// In-register DFTs.  Output X[q] is left at register position pos(q) (inv(p) is
+// the q held at position p): the radix-8/16 kernels finish in digit-swapped
+// order and their consumers index through pos(), which is free (compile-time
+// indices) where a transpose to natural order would cost 2R register moves.
 template <int R, int SIGN, typename T> struct Dft;
 
 template <int SIGN, typename T> struct Dft<2, SIGN, T> {
+    __host__ __device__ static constexpr int pos(int q) { return q; }
+    __host__ __device__ static constexpr int inv(int p) { return p; }
     __device__ __forceinline__ static void run(T *re, T *im)
     {
         T ar = re[0], ai = im[0];
@@ -99,6 +109,8 @@ template <int SIGN, typename T> struct Dft<2, SIGN, T> {
 };
 
 template <int SIGN, typename T> struct Dft<4, SIGN, T> {
+    __host__ __device__ static constexpr int pos(int q) { return q; }
+    __host__ __device__ static constexpr int inv(int p) { return p; }
     // stride lets the radix-8/16 kernels run it on interleaved sub-sequences
     template <int STRIDE = 1>
     __device__ __forceinline__ static void run(T *re, T *im)
@@ -121,6 +133,9 @@ template <int SIGN, typename T> struct Dft<4, SIGN, T> {
 
 // 8 = 4 x 2:  r = 2 r1 + r2,  q = q1 + 4 q2
 template <int SIGN, typename T> struct Dft<8, SIGN, T> {
+    // X[q1 + 4 q2] ends at 2 q1 + q2
+    __host__ __device__ static constexpr int pos(int q) { return 2 * (q & 3) + (q >> 2); }
+    __host__ __device__ static constexpr int inv(int p) { return (p >> 1) + 4 * (p & 1); }
     __device__ __forceinline__ static void run(T *re, T *im)
     {
         Dft<4, SIGN, T>::template run<2>(re, im);          // r2 = 0: elements 0,2,4,6
@@ -129,19 +144,20 @@ template <int SIGN, typename T> struct Dft<8, SIGN, T> {
         mul_w16<2, SIGN>(re[3], im[3]);
         mul_w16<4, SIGN>(re[5], im[5]);
         mul_w16<6, SIGN>(re[7], im[7]);
-        T xr[8], xi[8];
 #pragma unroll
-        for (int q1 = 0; q1 < 4; q1++) {
-            xr[q1] = re[2 * q1] + re[2 * q1 + 1];     xi[q1] = im[2 * q1] + im[2 * q1 + 1];
-            xr[q1 + 4] = re[2 * q1] - re[2 * q1 + 1]; xi[q1 + 4] = im[2 * q1] - im[2 * q1 + 1];
+        for (int q1 = 0; q1 < 4; q1++) {                   // 2-point DFT over r2, in place
+            const T ar = re[2 * q1], ai = im[2 * q1];
+            re[2 * q1] = ar + re[2 * q1 + 1];     im[2 * q1] = ai + im[2 * q1 + 1];
+            re[2 * q1 + 1] = ar - re[2 * q1 + 1]; im[2 * q1 + 1] = ai - im[2 * q1 + 1];
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) { re[j] = xr[j]; im[j] = xi[j]; }
     }
 };
 
 // 16 = 4 x 4:  r = 4 r1 + r2,  q = q1 + 4 q2
 template <int SIGN, typename T> struct Dft<16, SIGN, T> {
+    // X[q1 + 4 q2] ends at 4 q1 + q2 (an involution)
+    __host__ __device__ static constexpr int pos(int q) { return 4 * (q & 3) + (q >> 2); }
+    __host__ __device__ static constexpr int inv(int p) { return 4 * (p & 3) + (p >> 2); }
     __device__ __forceinline__ static void run(T *re, T *im)
     {
         // step 1: for each r2, 4-point DFT over r1 (elements r2, r2+4, r2+8, r2+12):
@@ -155,18 +171,11 @@ template <int SIGN, typename T> struct Dft<16, SIGN, T> {
         mul_w16<2, SIGN>(re[9], im[9]);   mul_w16<4, SIGN>(re[10], im[10]); mul_w16<6, SIGN>(re[11], im[11]);
         mul_w16<3, SIGN>(re[13], im[13]); mul_w16<6, SIGN>(re[14], im[14]); mul_w16<9, SIGN>(re[15], im[15]);
         // step 3: for each q1, 4-point DFT over r2 (contiguous 4 q1 .. 4 q1 + 3):
-        // X[q1 + 4 q2] lands at 4 q1 + q2  -> transpose to natural order
+        // X[q1 + 4 q2] lands at 4 q1 + q2 and stays there (see pos())
         Dft<4, SIGN, T>::template run<1>(re, im);
         Dft<4, SIGN, T>::template run<1>(re + 4, im + 4);
         Dft<4, SIGN, T>::template run<1>(re + 8, im + 8);
         Dft<4, SIGN, T>::template run<1>(re + 12, im + 12);
-        T xr[16], xi[16];
-#pragma unroll
-        for (int q1 = 0; q1 < 4; q1++)
-#pragma unroll
-            for (int q2 = 0; q2 < 4; q2++) { xr[q1 + 4 * q2] = re[4 * q1 + q2]; xi[q1 + 4 * q2] = im[4 * q1 + q2]; }
-#pragma unroll
-        for (int j = 0; j < 16; j++) { re[j] = xr[j]; im[j] = xi[j]; }
     }
 };
 
@@ -198,7 +207,12 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     }
     __host__ __device__ static constexpr int twsize() { return twoff(NP); }
 
-    __device__ __forceinline__ static int phys(int i) { return i ^ ((i >> 4) & 15); }
+    // LDS placement of logical index i: one element of padding per 32.  Every
+    // access pattern of the passes then is "per-thread base + compile-time offset"
+    // (no per-element address arithmetic); all of them are bank-conflict free
+    // except the stride-R writes of the first pass (2-way).
+    static constexpr int LDS_ELEMS = M + M / 32;
+    __device__ __forceinline__ static int phys(int i) { return i + (i >> 5); }
 
     // logical index held in register slot e before pass 0
     __device__ __forceinline__ static int in_index(int tid, int e)
@@ -210,7 +224,7 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     __device__ __forceinline__ static int out_index(int tid, int e)
     {
         constexpr int R = radix(NP - 1);
-        return (tid + (e / R) * NT) + (e % R) * (M / R);
+        return (tid + (e / R) * NT) + Dft<R, SIGN, T>::inv(e % R) * (M / R);
     }
 
     template <int S>
@@ -242,7 +256,7 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
             const int i = tid + b * NT, k = i & (p - 1);
 #pragma unroll
             for (int q = 0; q < R; q++) {
-                V2 v; v.x = re[b * R + q]; v.y = im[b * R + q];
+                V2 v; v.x = re[b * R + Dft<R, SIGN, T>::pos(q)]; v.y = im[b * R + Dft<R, SIGN, T>::pos(q)];
                 lds[phys((i - k) * R + k + q * p)] = v;
             }
         }

@@ -10,9 +10,24 @@ namespace bfir {
 // bfoverflow_t (brutefir/global.h:96-102) by the host.
 struct DevOverflow {
     unsigned int n_overflows;          // samples with |y| > max
-    unsigned int pad;
+    int intlargest;                    // integer outputs: largest unclipped |sample|
     unsigned long long largest_bits;   // bit pattern of max |y| (float widened, or double)
 };
+
+// Sample formats (brutefir/global.h:24-34; table of brutefir.cpp:435-538, little-endian host).
+struct FmtInfo { int bytes; bool isfloat; bool big_endian; };
+inline FmtInfo fmt_info(int fmt)
+{
+    static const int b[12] = {0, 1, 2, 2, 3, 3, 4, 4, 4, 4, 8, 8};
+    FmtInfo f;
+    f.bytes = (fmt >= 1 && fmt <= 11) ? b[fmt] : 0;
+    f.isfloat = fmt >= 8 && fmt <= 11;
+    f.big_endian = fmt == 3 || fmt == 5 || fmt == 7 || fmt == 9 || fmt == 11;
+    return f;
+}
+// get_full_scale (brutefir.cpp:395-398) in the reference's int arithmetic: negative for 32 bits.
+inline double fmt_full_scale(int fmt) { return (double)(int32_t)(1u << (8 * fmt_info(fmt).bytes - 1)); }
+inline bool fmt_is_native(int fmt) { return fmt == 8 || fmt == 10; }   // FLOAT_LE, FLOAT64_LE: fast staging kernels
 
 // Twiddle tables of one transform size / precision, resident in HBM.
 struct FftPlan {
@@ -31,11 +46,12 @@ int  fft_threads(int log2m);
 // buffer at raw + e*eng_stride_bytes.  dst[gc][dst_off + f], gc = e*C + c.
 struct StageInArgs {
     const void *raw; long eng_stride_bytes; long frame_off;
-    int n_eng, C, raw_bytes;       // raw_bytes 4 (FLOAT_LE) or 8 (FLOAT64_LE)
+    int n_eng, C, raw_bytes;       // raw_bytes: bytes per raw sample
     int spacing;                   // samples between frames (buffer_format_t.sample_spacing)
     long n_frames;
     void *dst; long dst_ch_stride; long dst_off;   // in reals
     int realsize;
+    int fmt = 0;                   // BF_SAMPLE_FORMAT_* code; 0 = FLOAT_LE / FLOAT64_LE by raw_bytes
 };
 void launch_stage_in(const StageInArgs &a, hipStream_t s);
 
@@ -52,6 +68,7 @@ struct StageOutArgs {
     DevOverflow *overflow;         // [n_eng*C]
     int *bad_block;                // atomicMin of the first block with a non-finite sample 0
     int block_base;                // index of the chunk's first block within the run
+    int fmt = 0;                   // BF_SAMPLE_FORMAT_* code; 0 = FLOAT_LE / FLOAT64_LE by raw_bytes
 };
 void launch_stage_out(const StageOutArgs &a, hipStream_t s);
 

@@ -77,7 +77,7 @@ int fft_plan_create(FftPlan *plan, int filter_length, int realsize)
     if ((1 << lg) != filter_length || lg < BFIR_MIN_LOG2M || lg > BFIR_MAX_LOG2M) return -1;
     if (realsize != 4 && realsize != 8) return -1;
     // one transform's LDS buffer must fit: M complex values
-    if ((size_t)filter_length * 2 * (size_t)realsize > 160 * 1024) return -1;
+    if (((size_t)filter_length + (size_t)filter_length / 32) * 2 * (size_t)realsize > 160 * 1024) return -1;
     std::vector<long double> tw, ws;
     switch (lg) {
 #define F(lgv) case lgv: fill_tw<lgv>(tw); break;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
     using V2 = typename Vec2<T>::type;
     using V4 = typename Vec4<T>::type;
     constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
-    __shared__ __attribute__((aligned(16))) V2 lds[M];
+    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
 
     const int tid = threadIdx.x;
     const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
@@ -191,7 +191,7 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
 {
     using V2 = typename Vec2<T>::type;
     // a transform whose LDS buffer would not fit one CU is never instantiated
-    if constexpr (sizeof(T) * 2 * (size_t(1) << LOG2M) <= 160 * 1024)
+    if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
         hipLaunchKernelGGL((k_fwd<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
                            (const V2 *)plan.tw, (const V2 *)plan.ws);
 }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
     using V2 = typename Vec2<T>::type;
     using V4 = typename Vec4<T>::type;
     constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
-    __shared__ __attribute__((aligned(16))) V2 lds[M];
+    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
 
     const int tid = threadIdx.x;
     const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
@@ -271,7 +271,7 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
 {
     using V2 = typename Vec2<T>::type;
     // a transform whose LDS buffer would not fit one CU is never instantiated
-    if constexpr (sizeof(T) * 2 * (size_t(1) << LOG2M) <= 160 * 1024)
+    if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
         hipLaunchKernelGGL((k_inv<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
                            (const V2 *)plan.tw, (const V2 *)plan.ws);
 }
@@ -686,9 +686,48 @@ template <typename TR, typename T> static void launch_stage_in_t(const StageInAr
     else hipLaunchKernelGGL((k_stage_in<TR, T, 4>), grid, block, 0, s, a);
 }
 
+// ---- any of the eleven sample formats ---------------------
+// Integer and big-endian formats take this byte-wise path: one thread per frame,
+// each sample assembled from its bytes.  (raw2real.cpp:30-424.)  Integer samples
+// keep their integer value; the 1/2^(bits-1) scale is applied by k_fwd.
+template <typename T>
+__device__ __forceinline__ T decode_sample(const unsigned char *p, int fmt, int bytes, bool be)
+{
+    unsigned long long u = 0;
+    for (int k = 0; k < bytes; k++) u |= (unsigned long long)p[be ? bytes - 1 - k : k] << (8 * k);
+    switch (fmt) {
+    case 1: return (T)(int)(signed char)u;
+    case 2: case 3: return (T)(int)(short)u;
+    case 4: case 5: return (T)(((int)((unsigned int)u << 8)) >> 8);     // sign-extended 24 bit
+    case 6: case 7: return (T)(int)(unsigned int)u;
+    case 8: case 9: return (T)__uint_as_float((unsigned int)u);
+    default: return (T)__longlong_as_double((long long)u);
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_in_fmt(StageInArgs a, int bytes, bool be)
+{
+    const int C = a.C, e = blockIdx.y;
+    const unsigned char *__restrict__ raw = (const unsigned char *)a.raw + (long)e * a.eng_stride_bytes +
+                                            a.frame_off * a.spacing * (long)bytes;
+    T *__restrict__ dst = (T *)a.dst + (long)e * C * a.dst_ch_stride + a.dst_off;
+    const long step = (long)gridDim.x * STAGE_THREADS;
+    for (long f = (long)blockIdx.x * STAGE_THREADS + threadIdx.x; f < a.n_frames; f += step)
+        for (int c = 0; c < C; c++)
+            dst[(long)c * a.dst_ch_stride + f] = decode_sample<T>(raw + (f * a.spacing + c) * (long)bytes, a.fmt, bytes, be);
+}
+
 void launch_stage_in(const StageInArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
+    if (a.fmt != 0 && !fmt_is_native(a.fmt)) {
+        const FmtInfo fi = fmt_info(a.fmt);
+        const long nb = (a.n_frames + STAGE_THREADS - 1) / STAGE_THREADS;
+        dim3 grid((unsigned)(nb < 2048 ? nb : 2048), a.n_eng), block(STAGE_THREADS);
+        if (a.realsize == 4) hipLaunchKernelGGL(k_stage_in_fmt<float>, grid, block, 0, s, a, fi.bytes, fi.big_endian);
+        else hipLaunchKernelGGL(k_stage_in_fmt<double>, grid, block, 0, s, a, fi.bytes, fi.big_endian);
+        return;
+    }
     const long nblk = (a.n_frames + STAGE_THREADS - 1) / STAGE_THREADS;
     dim3 grid((unsigned)(nblk < 2048 ? nblk : 2048), a.n_eng);
     const int wb = stage_word_bytes(a.raw, a.eng_stride_bytes, a.frame_off, a.C, a.spacing, a.raw_bytes);
@@ -776,9 +815,106 @@ template <typename T, typename TR> static void launch_stage_out_t(const StageOut
     else hipLaunchKernelGGL((k_stage_out<T, TR, 4>), grid, block, 0, s, a);
 }
 
+// Any output format, no dither (real2raw.cpp:342-922, 947-1224).  Integer formats use
+// dither{f,d}_real2int_no_dither (dither.cpp:196-262, 346-416): add 0.5, truncate toward
+// zero, step negatives down by one, clip; n_overflows / largest count clipped samples,
+// intlargest the largest unclipped |sample|.
+template <typename T> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_out_fmt(StageOutArgs a, int bytes, bool be, bool isfloat)
+{
+    using Bits = decltype(abs_bits((T)0));
+    __shared__ Bits red_max[STAGE_THREADS / 64][BFIR_MAXCH];
+    __shared__ unsigned int red_cnt[STAGE_THREADS / 64][BFIR_MAXCH];
+    __shared__ int red_int[STAGE_THREADS / 64][BFIR_MAXCH];
+    const int tid = threadIdx.x, e = blockIdx.y, C = a.C;
+    const int bits = 8 * bytes;
+    const int imin = (int)(0u - (1u << (bits - 1))), imax = (int)((1u << (bits - 1)) - 1u);
+    const T rmax = isfloat ? (T)a.max : (T)imax, rmin = isfloat ? (T)(-a.max) : (T)imin;
+    unsigned char *__restrict__ raw = (unsigned char *)a.raw + (long)e * a.eng_stride_bytes +
+                                      a.frame_off * a.spacing * (long)bytes;
+    const T *__restrict__ src = (const T *)a.src + (long)e * C * a.src_ch_stride;
+    Bits mx[BFIR_MAXCH];
+    unsigned int cnt[BFIR_MAXCH];
+    int imx[BFIR_MAXCH];
+#pragma unroll
+    for (int c = 0; c < BFIR_MAXCH; c++) { mx[c] = 0; cnt[c] = 0u; imx[c] = 0; }
+    const long step = (long)gridDim.x * STAGE_THREADS;
+    for (long f = (long)blockIdx.x * STAGE_THREADS + tid; f < a.n_frames; f += step) {
+        const bool first_of_block = (f % a.L) == 0;
+#pragma unroll
+        for (int c = 0; c < BFIR_MAXCH; c++) {
+            if (c < C) {
+                T v = src[(long)c * a.src_ch_stride + f];
+                if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+                unsigned long long u;
+                if (isfloat) {
+                    cnt[c] += ((v < (T)0) ? (v < rmin) : (v > rmax)) ? 1u : 0u;
+                    const Bits b = (v == v) ? abs_bits(v) : (Bits)0;
+                    mx[c] = b > mx[c] ? b : mx[c];
+                    if (bytes == 4) u = __float_as_uint((float)v);
+                    else u = (unsigned long long)__double_as_longlong((double)v);
+                } else {
+                    int smp;
+                    v += (T)0.5;
+                    if (v < (T)0) {
+                        if (v <= rmin) { smp = imin; cnt[c] += 1u; const Bits b = abs_bits(v); mx[c] = b > mx[c] ? b : mx[c]; }
+                        else { smp = (int)v - 1; imx[c] = -smp > imx[c] ? -smp : imx[c]; }
+                    } else {
+                        if (v > rmax) { smp = imax; cnt[c] += 1u; const Bits b = abs_bits(v); mx[c] = b > mx[c] ? b : mx[c]; }
+                        else { smp = (int)v; imx[c] = smp > imx[c] ? smp : imx[c]; }
+                    }
+                    u = (unsigned int)smp;
+                }
+                unsigned char *p = raw + (f * a.spacing + c) * (long)bytes;
+                for (int k = 0; k < bytes; k++) p[k] = (unsigned char)(u >> (8 * (be ? bytes - 1 - k : k)));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < BFIR_MAXCH; c++) {
+        if (c < C) {
+            Bits m = mx[c];
+            unsigned int n = cnt[c];
+            int im = imx[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const Bits om = __shfl_xor(m, o);
+                m = om > m ? om : m;
+                n += __shfl_xor(n, o);
+                const int oi = __shfl_xor(im, o);
+                im = oi > im ? oi : im;
+            }
+            if ((tid & 63) == 0) { red_max[tid >> 6][c] = m; red_cnt[tid >> 6][c] = n; red_int[tid >> 6][c] = im; }
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        Bits m = 0;
+        unsigned int n = 0u;
+        int im = 0;
+        for (int w = 0; w < STAGE_THREADS / 64; w++) {
+            m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; im = red_int[w][tid] > im ? red_int[w][tid] : im;
+        }
+        DevOverflow *of = a.overflow + (e * C + tid);
+        if (n) atomicAdd(&of->n_overflows, n);
+        if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
+            atomicMax(&of->largest_bits, (unsigned long long)m);
+        if (im > *(volatile int *)&of->intlargest) atomicMax(&of->intlargest, im);
+    }
+}
+
 void launch_stage_out(const StageOutArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
+    if (a.fmt != 0 && !fmt_is_native(a.fmt)) {
+        const FmtInfo fi = fmt_info(a.fmt);
+        const long nb = (a.n_frames + 4 * STAGE_THREADS - 1) / (4 * STAGE_THREADS);
+        dim3 grid((unsigned)(nb < 2048 ? (nb > 0 ? nb : 1) : 2048), a.n_eng), block(STAGE_THREADS);
+        if (a.realsize == 4)
+            hipLaunchKernelGGL(k_stage_out_fmt<float>, grid, block, 0, s, a, fi.bytes, fi.big_endian, fi.isfloat);
+        else
+            hipLaunchKernelGGL(k_stage_out_fmt<double>, grid, block, 0, s, a, fi.bytes, fi.big_endian, fi.isfloat);
+        return;
+    }
     // a few frames per thread so the per-block reduction is amortised
     const long nblk = (a.n_frames + 4 * STAGE_THREADS - 1) / (4 * STAGE_THREADS);
     dim3 grid((unsigned)(nblk < 2048 ? (nblk > 0 ? nblk : 1) : 2048), a.n_eng);

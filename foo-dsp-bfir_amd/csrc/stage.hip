@@ -104,9 +104,11 @@ static int need_raw(bfir_convolver *c, size_t bytes)
 static int check_bf(const bfir_buffer_format *bf)
 {
     if (!bf) return BFIR_ERR_ARG;
-    // only the float formats without byte swap (raw2real.cpp:52-55, 274-277)
-    if (!bf->sf.isfloat || bf->sf.swap || (bf->sf.bytes != 4 && bf->sf.bytes != 8) ||
-        bf->sf.bytes != bf->sf.sbytes || bf->sample_spacing < 1 || bf->byte_offset < 0)
+    // any of the eleven formats, described consistently with setup_sample_format
+    // (brutefir.cpp:435-538): sbytes == bytes (no shift), swap set for the *_BE codes
+    const FmtInfo fi = fmt_info(bf->sf.format);
+    if (fi.bytes == 0 || bf->sf.bytes != fi.bytes || bf->sf.sbytes != fi.bytes || bf->sf.isfloat != fi.isfloat ||
+        bf->sf.swap != fi.big_endian || bf->sample_spacing < 1 || bf->byte_offset < 0)
         return BFIR_ERR_UNSUPPORTED;
     return BFIR_OK;
 }
@@ -124,7 +126,7 @@ extern "C" int bfir_convolver_raw2cbuf(bfir_convolver *c, const void *rawbuf, vo
     HIP_TRY(hipMemcpyAsync(c->d_raw, (const char *)rawbuf + bf->byte_offset, span, hipMemcpyHostToDevice, c->stream));
     StageInArgs a;
     a.raw = c->d_raw; a.eng_stride_bytes = 0; a.frame_off = 0;
-    a.n_eng = 1; a.C = 1; a.raw_bytes = bf->sf.bytes; a.spacing = bf->sample_spacing;
+    a.n_eng = 1; a.C = 1; a.raw_bytes = bf->sf.bytes; a.spacing = bf->sample_spacing; a.fmt = bf->sf.format;
     a.n_frames = c->L;
     a.dst = c->d[0]; a.dst_ch_stride = c->N; a.dst_off = 0;
     a.realsize = c->s;
@@ -235,7 +237,7 @@ extern "C" int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void
     HIP_TRY(hipMemsetAsync(c->d_bad, 0x7f, sizeof(int), c->stream));
     StageOutArgs a;
     a.raw = c->d_raw; a.eng_stride_bytes = 0; a.frame_off = 0;
-    a.n_eng = 1; a.C = 1; a.raw_bytes = bf->sf.bytes; a.spacing = bf->sample_spacing;
+    a.n_eng = 1; a.C = 1; a.raw_bytes = bf->sf.bytes; a.spacing = bf->sample_spacing; a.fmt = bf->sf.format;
     a.n_frames = c->L;
     a.src = c->d[0]; a.src_ch_stride = c->N;
     a.realsize = c->s; a.L = c->L; a.max = overflow->max;
@@ -251,6 +253,7 @@ extern "C" int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void
     if (c->s == 4) { unsigned int u = (unsigned int)h.largest_bits; float f; memcpy(&f, &u, 4); largest = (double)f; }
     else memcpy(&largest, &h.largest_bits, 8);
     if (largest > overflow->largest) overflow->largest = largest;
+    if (h.intlargest > overflow->intlargest) overflow->intlargest = h.intlargest;   // dither.cpp:224-227, 246-249
     return BFIR_OK;
 }
 

@@ -16,8 +16,17 @@ def _real_dtype(realsize):
     return np.float32 if realsize == 4 else np.float64
 
 
-def _fmt_dtype(fmt):
-    return {SAMPLE_FORMAT_FLOAT_LE: np.float32, SAMPLE_FORMAT_FLOAT64_LE: np.float64}[fmt]
+# raw sample element types (brutefir/global.h:24-34); 24-bit samples are 3 raw bytes
+_FMT_DTYPES = {1: np.dtype("i1"), 2: np.dtype("<i2"), 3: np.dtype(">i2"), 4: None, 5: None,
+               6: np.dtype("<i4"), 7: np.dtype(">i4"), 8: np.dtype("<f4"), 9: np.dtype(">f4"),
+               10: np.dtype("<f8"), 11: np.dtype(">f8")}
+
+
+def raw_frames(fmt, shape_frames_channels):
+    """Zeroed interleaved raw buffer [..., frames, C] (plus a trailing 3 for 24-bit formats)."""
+    d = _FMT_DTYPES[fmt]
+    shape = tuple(shape_frames_channels)
+    return np.zeros(shape + (3,), np.uint8) if d is None else np.zeros(shape, d)
 
 
 class Brutefir:
@@ -80,12 +89,14 @@ class Brutefir:
         """run(void *inbuf, void *outbuf) for every L-frame block in `inbuf`
         (host arrays).  inbuf: [n_blocks*L, C] (one engine) or
         [n_engines, n_blocks*L, C].  Returns (rc, outbuf)."""
-        x = np.ascontiguousarray(inbuf, dtype=_fmt_dtype(self.in_format))
-        frames = x.shape[-2]
-        assert x.shape[-1] == self.C and frames % self.L == 0
-        assert x.size == self.n_engines * frames * self.C
+        d_in = _FMT_DTYPES[self.in_format]
+        x = np.ascontiguousarray(inbuf, dtype=np.uint8 if d_in is None else d_in)
+        shape = x.shape[:-1] if d_in is None else x.shape        # 24-bit: [..., frames, C, 3]
+        frames = shape[-2]
+        assert shape[-1] == self.C and frames % self.L == 0
+        assert int(np.prod(shape)) == self.n_engines * frames * self.C
         if outbuf is None:
-            outbuf = np.zeros(x.shape, dtype=_fmt_dtype(self.out_format))
+            outbuf = raw_frames(self.out_format, shape)
         rc = self._lib.bfir_engine_run(self._h, x.ctypes.data, outbuf.ctypes.data, frames // self.L)
         return rc, outbuf
 

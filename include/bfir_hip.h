@@ -33,8 +33,17 @@ extern "C" {
 
 /* limits and sample format codes: brutefir/global.h:21-34 */
 #define BFIR_MAXCHANNELS 8
+#define BFIR_SAMPLE_FORMAT_S8 1
+#define BFIR_SAMPLE_FORMAT_S16_LE 2
+#define BFIR_SAMPLE_FORMAT_S16_BE 3
+#define BFIR_SAMPLE_FORMAT_S24_LE 4
+#define BFIR_SAMPLE_FORMAT_S24_BE 5
+#define BFIR_SAMPLE_FORMAT_S32_LE 6
+#define BFIR_SAMPLE_FORMAT_S32_BE 7
 #define BFIR_SAMPLE_FORMAT_FLOAT_LE 8
+#define BFIR_SAMPLE_FORMAT_FLOAT_BE 9
 #define BFIR_SAMPLE_FORMAT_FLOAT64_LE 10
+#define BFIR_SAMPLE_FORMAT_FLOAT64_BE 11
 
 /* mixmodes: brutefir/fftw_convolver.hpp:14-16 */
 #define BFIR_MIXMODE_INPUT 1
@@ -92,8 +101,10 @@ typedef struct bfir_engine bfir_engine;
 /* brutefir::brutefir (brutefir/brutefir.hpp:18-25, brutefir.cpp:21-44).
  * filter_length: partition length L (power of two, 16..16384; 8192 max for
  * realsize 8); filter_blocks: B; realsize: 4 or 8; channels: 1..8;
- * in/out_format: BFIR_SAMPLE_FORMAT_FLOAT_LE or _FLOAT64_LE; apply_dither
- * must be 0 (dither only acts on integer outputs).  device: HIP ordinal.
+ * in/out_format: any BFIR_SAMPLE_FORMAT_* code (FLOAT_LE / FLOAT64_LE take the
+ * vectorised staging kernels, the others a byte-wise one); apply_dither with an
+ * integer output format is refused (the reference's dither path dereferences a
+ * table pointer it never sets, dither.cpp:190-194).  device: HIP ordinal.
  * Returns NULL and sets *err on failure. */
 bfir_engine *bfir_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
                                 int in_format, int out_format, int sampling_rate, int apply_dither,

@@ -16,6 +16,26 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* Sample format table: brutefir::setup_sample_format (brutefir/brutefir.cpp:435-538)
+ * with the codes of brutefir/global.h:24-34.  `swap` is set for the *_BE formats,
+ * i.e. the table assumes a little-endian host, like the reference's Win32 build. */
+int orc_fmt_bytes(int fmt)
+{
+    static const int b[12] = {0, 1, 2, 2, 3, 3, 4, 4, 4, 4, 8, 8};
+    return (fmt >= 1 && fmt <= 11) ? b[fmt] : 0;
+}
+int orc_fmt_isfloat(int fmt) { return fmt >= 8 && fmt <= 11; }
+int orc_fmt_swap(int fmt) { return fmt == 3 || fmt == 5 || fmt == 7 || fmt == 9 || fmt == 11; }
+/* get_full_scale (brutefir.cpp:395-398): (double)(1 << (bits-1)) in int arithmetic,
+ * which is NEGATIVE for 32-bit samples (1 << 31 wraps); kept, the two scales cancel. */
+double orc_fmt_full_scale(int fmt)
+{
+    return (double)(int32_t)(1u << (8 * orc_fmt_bytes(fmt) - 1));
+}
+double orc_fmt_in_scale(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : 1.0 / orc_fmt_full_scale(fmt); }
+double orc_fmt_out_scale(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_scale(fmt); }
+double orc_fmt_max(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_scale(fmt) - 1.0; }
+
 #define REAL float
 #define SUF(x) x##_f
 #include "bfir_oracle_impl.inc"
@@ -35,6 +55,7 @@
 struct orc_engine {
     int L, N, B, s, C;
     int in_bytes, out_bytes;         /* raw sample widths                    */
+    int in_fmt, out_fmt;             /* BF_SAMPLE_FORMAT_* codes             */
     double in_scale, out_scale;      /* sample_format_t.scale                */
     int curbuf;
     unsigned int blockcounter;
@@ -49,13 +70,7 @@ struct orc_engine {
     int initialized;
 };
 
-static int fmt_bytes(int fmt)
-{
-    /* brutefir/brutefir.cpp:512-538: the two formats on the measured path */
-    if (fmt == ORC_FMT_FLOAT_LE) return 4;
-    if (fmt == ORC_FMT_FLOAT64_LE) return 8;
-    return 0;
-}
+static int fmt_bytes(int fmt) { return orc_fmt_bytes(fmt); }
 
 orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
                               int in_format, int out_format)
@@ -73,7 +88,9 @@ orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize
     e->L = filter_length; e->N = 2 * filter_length; e->B = filter_blocks;
     e->s = realsize; e->C = channels;
     e->in_bytes = fmt_bytes(in_format); e->out_bytes = fmt_bytes(out_format);
-    e->in_scale = 1.0; e->out_scale = 1.0;                      /* float formats: scale 1 */
+    e->in_fmt = in_format; e->out_fmt = out_format;
+    /* setup_input: normalised scale; setup_output: full scale (brutefir.cpp:546-582) */
+    e->in_scale = orc_fmt_in_scale(in_format); e->out_scale = orc_fmt_out_scale(out_format);
     cb = (size_t)e->N * (size_t)e->s;                           /* convolver_cbufsize */
     for (n = 0; n < e->C; n++) {
         /* brutefir.cpp:758-807: zero-initialised work buffers; with one
@@ -82,7 +99,7 @@ orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize
         e->ocbuf[n] = (e->B > 1) ? (uint8_t *)calloc(1, cb) : e->fdl[n];
         e->timebuf[n][0] = (uint8_t *)calloc(1, cb);
         e->timebuf[n][1] = (uint8_t *)calloc(1, cb);
-        e->overflow[n].max = 1.0;                               /* brutefir.cpp:674-678 */
+        e->overflow[n].max = orc_fmt_max(out_format);           /* brutefir.cpp:672-684 */
     }
     e->ifreq = (uint8_t *)calloc(1, cb);
     e->ofreq = (uint8_t *)calloc(1, cb);
@@ -194,12 +211,12 @@ int orc_engine_run(orc_engine *e, const void *inbuf, void *outbuf)
         int curblock, finite;
         /* :255-263 staging in + forward transform */
         if (e->s == 4) {
-            orc_raw2cbuf_f(e->L, inbuf, n * e->in_bytes, e->in_bytes, e->C,
-                           (float *)tcur, (float *)tnext);
+            orc_raw2real_fmt_f((float *)tnext, (const uint8_t *)inbuf + n * e->in_bytes, e->in_fmt, e->C, e->L);
+            memcpy((float *)tcur + e->L, tnext, sizeof(float) * (size_t)e->L);   /* fftw_convolver.cpp:184 */
             orc_r2hc_f(e->N, (const float *)tcur, (float *)e->ifreq);
         } else {
-            orc_raw2cbuf_d(e->L, inbuf, n * e->in_bytes, e->in_bytes, e->C,
-                           (double *)tcur, (double *)tnext);
+            orc_raw2real_fmt_d((double *)tnext, (const uint8_t *)inbuf + n * e->in_bytes, e->in_fmt, e->C, e->L);
+            memcpy((double *)tcur + e->L, tnext, sizeof(double) * (size_t)e->L);
             orc_r2hc_d(e->N, (const double *)tcur, (double *)e->ifreq);
         }
         if (e->procblocks[n] < e->B) e->procblocks[n]++;       /* :265-268 */
@@ -245,11 +262,11 @@ int orc_engine_run(orc_engine *e, const void *inbuf, void *outbuf)
         if (!finite) return -1;
         /* :326-334 staging out: the first L samples are the valid half */
         if (e->s == 4)
-            orc_real2raw_f((uint8_t *)outbuf + n * e->out_bytes, (const float *)e->tout,
-                           e->out_bytes, e->C, e->L, &e->overflow[n]);
+            orc_real2raw_fmt_f((uint8_t *)outbuf + n * e->out_bytes, (const float *)e->tout,
+                               e->out_fmt, e->C, e->L, &e->overflow[n]);
         else
-            orc_real2raw_d((uint8_t *)outbuf + n * e->out_bytes, (const double *)e->tout,
-                           e->out_bytes, e->C, e->L, &e->overflow[n]);
+            orc_real2raw_fmt_d((uint8_t *)outbuf + n * e->out_bytes, (const double *)e->tout,
+                               e->out_fmt, e->C, e->L, &e->overflow[n]);
     }
     e->curbuf = !e->curbuf;                                    /* :337 */
     e->blockcounter++;                                         /* :340 */

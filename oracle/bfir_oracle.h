@@ -92,6 +92,22 @@ void orc_real2raw_f(void *raw, const float *real, int raw_bytes, int spacing, in
 void orc_real2raw_d(void *raw, const double *real, int raw_bytes, int spacing, int n,
                     orc_overflow_t *of);
 
+/* ---- all eleven sample formats ----
+ * Format table of brutefir::setup_sample_format (brutefir/brutefir.cpp:435-538). */
+int orc_fmt_bytes(int fmt);
+int orc_fmt_isfloat(int fmt);
+int orc_fmt_swap(int fmt);
+double orc_fmt_in_scale(int fmt);   /* normalised: 1 / 2^(bits-1) for integers */
+double orc_fmt_out_scale(int fmt);  /* full scale: 2^(bits-1) for integers     */
+double orc_fmt_max(int fmt);        /* bfoverflow_t.max (brutefir.cpp:672-684) */
+/* raw2real{f,d} and real2raw{f,d}_no_dither for any format (raw2real.cpp:30-424,
+ * real2raw.cpp:342-1224 with dither.cpp:196-262, 346-416).  `raw` points at the
+ * channel's first sample; spacing in samples. */
+void orc_raw2real_fmt_f(float *real, const void *raw, int fmt, int spacing, int n);
+void orc_raw2real_fmt_d(double *real, const void *raw, int fmt, int spacing, int n);
+void orc_real2raw_fmt_f(void *raw, const float *real, int fmt, int spacing, int n, orc_overflow_t *of);
+void orc_real2raw_fmt_d(void *raw, const double *real, int fmt, int spacing, int n, orc_overflow_t *of);
+
 /* ---- engine level: brutefir::brutefir / set_coeff / run / reset ---- */
 typedef struct orc_engine orc_engine;
 

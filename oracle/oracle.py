@@ -71,6 +71,11 @@ def lib():
             "orc_engine_get_overflow": (None, [vp, ci, C.POINTER(Overflow)]),
             "orc_engine_coeff_block": (vp, [vp, ci, ci]),
             "orc_direct_conv": (None, [vp, ci, vp, ci, vp]),
+            "orc_raw2real_fmt_f": (None, [vp, vp, ci, ci, ci]),
+            "orc_raw2real_fmt_d": (None, [vp, vp, ci, ci, ci]),
+            "orc_real2raw_fmt_f": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
+            "orc_real2raw_fmt_d": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
+            "orc_fmt_in_scale": (cd, [ci]), "orc_fmt_out_scale": (cd, [ci]), "orc_fmt_max": (cd, [ci]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -86,8 +91,42 @@ def real_dtype(realsize):
     return np.float32 if realsize == 4 else np.float64
 
 
+# numpy element type of a raw sample (brutefir/global.h:24-34); 24-bit samples are 3 raw bytes
+FMT_DTYPES = {1: np.dtype("i1"), 2: np.dtype("<i2"), 3: np.dtype(">i2"), 4: None, 5: None,
+              6: np.dtype("<i4"), 7: np.dtype(">i4"), 8: np.dtype("<f4"), 9: np.dtype(">f4"),
+              10: np.dtype("<f8"), 11: np.dtype(">f8")}
+FMT_BYTES = {1: 1, 2: 2, 3: 2, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 8, 11: 8}
+
+
 def fmt_dtype(fmt):
-    return {FMT_FLOAT_LE: np.float32, FMT_FLOAT64_LE: np.float64}[fmt]
+    d = FMT_DTYPES[fmt]
+    return np.dtype((np.uint8, 3)) if d is None else d
+
+
+def raw_frames(fmt, frames, channels):
+    """Zeroed interleaved raw buffer of `frames` x `channels` samples of format `fmt`."""
+    d = FMT_DTYPES[fmt]
+    return np.zeros((frames, channels, 3), np.uint8) if d is None else np.zeros((frames, channels), d)
+
+
+def encode_ints(values, fmt):
+    """Integer sample values [frames, C] -> raw buffer of an integer format."""
+    v = np.asarray(values, dtype=np.int64)
+    if FMT_DTYPES[fmt] is not None:
+        return v.astype(FMT_DTYPES[fmt])
+    u = (v & 0xFFFFFF).astype(np.uint32)
+    b = np.stack([(u >> s) & 0xFF for s in ((0, 8, 16) if fmt == 4 else (16, 8, 0))], axis=-1)
+    return b.astype(np.uint8)
+
+
+def decode_ints(raw, fmt):
+    """Raw buffer of an integer format -> int64 sample values [frames, C]."""
+    if FMT_DTYPES[fmt] is not None:
+        return np.asarray(raw).astype(np.int64)
+    r = np.asarray(raw).astype(np.int64)
+    lo, mid, hi = (r[..., 0], r[..., 1], r[..., 2]) if fmt == 4 else (r[..., 2], r[..., 1], r[..., 0])
+    v = lo | (mid << 8) | (hi << 16)
+    return np.where(v >= 1 << 23, v - (1 << 24), v)
 
 
 def _suf(dtype):
@@ -165,6 +204,23 @@ def real2raw(real, raw, channel, of):
                                                       raw.shape[1], real.size, C.byref(of))
 
 
+def raw2real_fmt(raw, channel, fmt, realsize):
+    """Channel `channel` of an interleaved raw buffer of any format -> working precision."""
+    n, spacing = raw.shape[0], raw.shape[1]
+    out = np.zeros(n, dtype=real_dtype(realsize))
+    base = raw.ctypes.data + channel * FMT_BYTES[fmt]
+    getattr(lib(), "orc_raw2real_fmt" + _suf(out.dtype))(_p(out), C.c_void_p(base), fmt, spacing, n)
+    return out
+
+
+def real2raw_fmt(real, raw, channel, fmt, of):
+    """Write `real` into channel `channel` of interleaved raw buffer `raw` (any format)."""
+    real = np.ascontiguousarray(real)
+    base = raw.ctypes.data + channel * FMT_BYTES[fmt]
+    getattr(lib(), "orc_real2raw_fmt" + _suf(real.dtype))(C.c_void_p(base), _p(real), fmt, raw.shape[1],
+                                                           real.size, C.byref(of))
+
+
 def direct_conv(x, h):
     x = np.ascontiguousarray(x, dtype=np.float64)
     h = np.ascontiguousarray(h, dtype=np.float64)
@@ -208,9 +264,12 @@ class Engine:
 
     def run(self, x):
         """x: [n_blocks*L, C] interleaved frames in the input format. Returns (rc, y)."""
-        x = np.ascontiguousarray(x, dtype=fmt_dtype(self.in_format))
-        assert x.ndim == 2 and x.shape[1] == self.C and x.shape[0] % self.L == 0
-        y = np.zeros(x.shape, dtype=fmt_dtype(self.out_format))
+        if FMT_DTYPES[self.in_format] is not None:
+            x = np.ascontiguousarray(x, dtype=FMT_DTYPES[self.in_format])
+        else:
+            x = np.ascontiguousarray(x, dtype=np.uint8)   # [frames, C, 3]
+        assert x.shape[1] == self.C and x.shape[0] % self.L == 0
+        y = raw_frames(self.out_format, x.shape[0], self.C)
         rc = lib().orc_engine_run_blocks(self.h, _p(x), _p(y), x.shape[0] // self.L)
         return rc, y
 

@@ -13,6 +13,7 @@
 
 #include "../../foo-dsp-bfir_amd/host/brutefir_hip.hpp"
 #include "../../foo-dsp-bfir_amd/host/coeff_hip.hpp"
+#include "../../foo-dsp-bfir_amd/host/preprocessor_hip.hpp"
 
 static int g_fail = 0;
 #define CHECK(cond, ...)                                        \
@@ -150,6 +151,30 @@ int main()
         bool threw = false;
         try { fftw_convolver c(1000, 4, nullptr); } catch (...) { threw = true; }
         CHECK(threw, "convolver ctor must throw on a bad length");
+    }
+    // offline drivers (preprocessor.cpp): a pure-gain impulse makes the expected answers exact
+    {
+        const int L = 256, C = 2, n = 600;
+        std::vector<float> ir((size_t)n * C, 0.f), noise((size_t)768 * C);
+        ir[0] = 4.0f; ir[1] = 2.0f;                       // channel gains 4 and 2 at tap 0
+        std::mt19937 rng(7); std::uniform_real_distribution<float> u(-1.f, 1.f);
+        float peak = 0;
+        for (size_t i = 0; i < noise.size(); i++) { noise[i] = u(rng); if (i % C == 0) peak = std::max(peak, std::fabs(noise[i])); }
+        double att = 1;
+        CHECK(preprocessor::calculate_attenuation(ir.data(), C, n, L, 4, noise.data(), &att), "calculate_attenuation");
+        CHECK(std::fabs(att + 20.0 * std::log10(4.0 * peak)) < 1e-4, "attenuation %g vs %g", att, -20.0 * std::log10(4.0 * peak));
+        std::vector<float> a((size_t)300 * C, 0.f), b((size_t)500 * C, 0.f);
+        a[0] = 0.5f; a[1] = 0.25f; b[2 * C] = 1.0f; b[2 * C + 1] = 1.0f;   // gain, then a 2-frame delay
+        std::vector<preprocessor::impulse_array> imps = {{a.data(), C, 300, 3.0}, {b.data(), C, 500, 1.0}};
+        std::vector<uint8_t> out; int oc = 0, of = 0;
+        CHECK(preprocessor::convolve_impulses(imps, L, 4, &out, &oc, &of), "convolve_impulses");
+        CHECK(oc == C && of == 500, "shape %d x %d", of, oc);
+        const float *o = (const float *)out.data();
+        // pass 1: dirac * a = a; coefficients become 3*a; pass 2: b * (3a) = 1.5 / 0.75 at frame 2
+        CHECK(std::fabs(o[2 * C] - 1.5f) < 1e-5 && std::fabs(o[2 * C + 1] - 0.75f) < 1e-5, "cascade %g %g", o[2 * C], o[2 * C + 1]);
+        double rest = 0;
+        for (int i = 0; i < 500 * C; i++) if (i != 2 * C && i != 2 * C + 1) rest = std::max(rest, (double)std::fabs(o[i]));
+        CHECK(rest < 1e-5, "cascade residue %g", rest);
     }
     printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
     return g_fail ? 1 : 0;

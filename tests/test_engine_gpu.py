@@ -234,4 +234,4 @@ def test_create_rejects_bad_arguments(bfir):
         with pytest.raises(bfir.BfirError):
             bfir.Brutefir(*args)
     with pytest.raises(bfir.BfirError):
-        bfir.Brutefir(1024, 2, 4, 2, in_format=2)   # S16_LE: not on the float path yet
+        bfir.Brutefir(1024, 2, 4, 2, in_format=12)  # not a BF_SAMPLE_FORMAT_* code

@@ -72,6 +72,12 @@ SIGNATURES = {
     "bfir_convolver_freq2time": (_ci, [_vp, _vp, _vp]),
     "bfir_convolver_cbuf2raw": (_ci, [_vp, _vp, _vp, C.POINTER(BufferFormat), C.POINTER(Overflow)]),
     "bfir_convolver_coeffs2cbuf": (_vp, [_vp, _vp, _ci, _cd, _vp]),
+    "bfir_convolver_runtime_coeffs2cbuf": (_ci, [_vp, _vp, _vp]),
+    "bfir_convolver_dirac_convolve": (_ci, [_vp, _vp, _vp]),
+    "bfir_convolver_dirac_convolve_inplace": (_ci, [_vp, _vp]),
+    "bfir_convolver_convolve_eval": (_ci, [_vp, _vp, _vp, _vp]),
+    "bfir_convolver_crossfade_inplace": (_ci, [_vp, _vp, _vp, _vp]),
+    "bfir_convolver_verify_cbuf": (_ci, [_vp, C.POINTER(_vp), _ci]),
     "bfir_aligned_malloc": (_vp, [C.c_size_t, C.c_size_t]),
     "bfir_aligned_free": (None, [_vp]),
 }

@@ -100,3 +100,33 @@ class FftwConvolver:
         p = self._lib.bfir_convolver_coeffs2cbuf(self._h, taps.ctypes.data, n_coeffs, float(scale),
                                                  self._buf(dest))
         return dest if p else None
+
+    # ---- declared by the reference, called by nothing in its tree ----
+    def convolver_runtime_coeffs2cbuf(self, src, dest):
+        self._chk(self._lib.bfir_convolver_runtime_coeffs2cbuf(self._h, src.ctypes.data, self._buf(dest)),
+                  "runtime_coeffs2cbuf")
+
+    def convolver_dirac_convolve(self, input_cbuf, output_cbuf):
+        self._chk(self._lib.bfir_convolver_dirac_convolve(self._h, self._buf(input_cbuf),
+                                                          self._buf(output_cbuf)), "dirac_convolve")
+
+    def convolver_dirac_convolve_inplace(self, cbuf):
+        self._chk(self._lib.bfir_convolver_dirac_convolve_inplace(self._h, self._buf(cbuf)), "dirac_convolve")
+
+    def convolver_convolve_eval(self, input_cbuf, buffer_cbuf, output_cbuf):
+        assert buffer_cbuf.size >= 3 * self.n_fft2 and buffer_cbuf.dtype == self.dtype
+        self._chk(self._lib.bfir_convolver_convolve_eval(self._h, self._buf(input_cbuf), buffer_cbuf.ctypes.data,
+                                                         self._buf(output_cbuf)), "convolve_eval")
+
+    def convolver_crossfade_inplace(self, input_cbuf, crossfade_cbuf, buffer_cbuf):
+        assert buffer_cbuf.size >= 3 * self.n_fft2 and buffer_cbuf.dtype == self.dtype
+        self._chk(self._lib.bfir_convolver_crossfade_inplace(self._h, self._buf(input_cbuf),
+                                                             self._buf(crossfade_cbuf), buffer_cbuf.ctypes.data),
+                  "crossfade_inplace")
+
+    def convolver_verify_cbuf(self, cbufs, n_cbufs):
+        ptrs = (C.c_void_p * n_cbufs)(*[self._buf(b) for b in cbufs[:n_cbufs]])
+        rc = self._lib.bfir_convolver_verify_cbuf(self._h, ptrs, n_cbufs)
+        if rc < 0:
+            raise BfirError(rc, "verify_cbuf")
+        return bool(rc)

@@ -113,6 +113,20 @@ void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
 void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_grouped, int realsize,
                     hipStream_t s);
 
+// SURVEY 8f row 3 (stage API only): N-input mixnscale, dirac_convolve, the blend of
+// crossfade_inplace, finite check.
+constexpr int BFIR_MAX_MIX = 32;
+struct MixArgs {
+    const void *in[BFIR_MAX_MIX];
+    double scale[BFIR_MAX_MIX];
+    int n;
+};
+void launch_reorder_n(const MixArgs &m, void *out, int n_fft, int to_grouped, int realsize, hipStream_t s);
+void launch_dirac(const void *in, void *out, int n_fft, int realsize, hipStream_t s);
+void launch_crossfade_blend(const void *crossfade_time, void *buffer_time, const void *buffer_tail, int n_fft2,
+                            int realsize, hipStream_t s);
+void launch_check_finite(const void *buf, int n, int realsize, int *bad, hipStream_t s);
+
 // One convolve / convolve_add / convolve_inplace call of the stage API with the
 // reference's exact operation order (separate multiplies and adds).
 // mode 0: d = b*c, mode 1: d += b*c.  d may alias b (in-place form).

@@ -959,6 +959,101 @@ void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_g
 }
 
 // ---------------------------------------------------------------------------
+// stage API, SURVEY 8f row 3: N-input mixnscale, dirac_convolve, crossfade blend,
+// finite check.  All keep the reference's operation order (separate roundings).
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b);   // separately rounded (defined below)
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b);
+
+template <typename T> __global__ void k_reorder_n(MixArgs m, T *__restrict__ out, int n_fft, int to_grouped)
+{
+    // brutefir/fftw_convolver.cpp:908-1156 (INPUT), :1187-1419 (OUTPUT): sum_i in_i * scale_i, left to right
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = n_fft >> 1;
+    if (k >= half) return;
+    const int gr = 8 * (k >> 2) + (k & 3);
+    T a = (T)0, b = (T)0;
+    for (int i = 0; i < m.n; i++) {
+        const T *in = (const T *)m.in[i];
+        const T sc = (T)m.scale[i];
+        T pa, pb;
+        if (to_grouped) { pa = mul_rn(in[k], sc); pb = mul_rn(k == 0 ? in[half] : in[n_fft - k], sc); }
+        else { pa = mul_rn(in[gr], sc); pb = mul_rn(in[gr + 4], sc); }
+        a = (i == 0) ? pa : add_rn(a, pa);
+        b = (i == 0) ? pb : add_rn(b, pb);
+    }
+    if (to_grouped) { out[gr] = a; out[gr + 4] = b; }
+    else { out[k] = a; if (k == 0) out[half] = b; else out[n_fft - k] = b; }
+}
+
+void launch_reorder_n(const MixArgs &m, void *out, int n_fft, int to_grouped, int realsize, hipStream_t s)
+{
+    const int half = n_fft / 2, threads = 256, blocks = (half + threads - 1) / threads;
+    if (realsize == 4) hipLaunchKernelGGL(k_reorder_n<float>, dim3(blocks), dim3(threads), 0, s, m, (float *)out, n_fft, to_grouped);
+    else hipLaunchKernelGGL(k_reorder_n<double>, dim3(blocks), dim3(threads), 0, s, m, (double *)out, n_fft, to_grouped);
+}
+
+template <typename T> __global__ void k_dirac(const T *in, T *out, int n_fft)
+{
+    // brutefir/fftw_convolver.cpp:1527-1556, 2222-2251
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fft) return;
+    const T fr = (T)(1.0 / (T)n_fft);
+    out[k] = mul_rn(in[k], (k & 1) ? -fr : fr);
+}
+
+void launch_dirac(const void *in, void *out, int n_fft, int realsize, hipStream_t s)
+{
+    const int threads = 256, blocks = (n_fft + threads - 1) / threads;
+    if (realsize == 4) hipLaunchKernelGGL(k_dirac<float>, dim3(blocks), dim3(threads), 0, s, (const float *)in, (float *)out, n_fft);
+    else hipLaunchKernelGGL(k_dirac<double>, dim3(blocks), dim3(threads), 0, s, (const double *)in, (double *)out, n_fft);
+}
+
+// the time-domain blend of convolver_crossfade_inplace (brutefir/fftw_convolver.cpp:296-315)
+__global__ void k_crossfade_blend_f(const float *cf, float *buf, int n_fft2)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_fft2) return;
+    const float f = (float)(1.0 / (double)(float)(n_fft2 - 1));
+    // crossfade[n] * (1.0 - f * (float)n) + buffer[n] * f * (float)n, with C's promotions
+    const double a = mul_rn((double)cf[n], add_rn(1.0, -(double)mul_rn(f, (float)n)));
+    const float b = mul_rn(mul_rn(buf[n], f), (float)n);
+    buf[n] = (float)add_rn(a, (double)b);
+}
+__global__ void k_crossfade_blend_d(double *buf1, const double *buf2, int n_fft2)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_fft2) return;
+    const double d = 1.0 / (double)(n_fft2 - 1);
+    buf1[n] = add_rn(mul_rn(buf1[n], add_rn(1.0, -mul_rn(d, (double)n))), mul_rn(mul_rn(buf2[n], d), (double)n));
+}
+
+void launch_crossfade_blend(const void *crossfade_time, void *buffer_time, const void *buffer_tail, int n_fft2,
+                            int realsize, hipStream_t s)
+{
+    const int threads = 256, blocks = (n_fft2 + threads - 1) / threads;
+    if (realsize == 4)
+        hipLaunchKernelGGL(k_crossfade_blend_f, dim3(blocks), dim3(threads), 0, s, (const float *)crossfade_time,
+                           (float *)buffer_time, n_fft2);
+    else
+        hipLaunchKernelGGL(k_crossfade_blend_d, dim3(blocks), dim3(threads), 0, s, (double *)buffer_time,
+                           (const double *)buffer_tail, n_fft2);
+}
+
+template <typename T> __global__ void k_check_finite(const T *buf, int n, int *bad)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && !isfinite((double)buf[k])) atomicExch(bad, 1);
+}
+
+void launch_check_finite(const void *buf, int n, int realsize, int *bad, hipStream_t s)
+{
+    const int threads = 256, blocks = (n + threads - 1) / threads;
+    if (realsize == 4) hipLaunchKernelGGL(k_check_finite<float>, dim3(blocks), dim3(threads), 0, s, (const float *)buf, n, bad);
+    else hipLaunchKernelGGL(k_check_finite<double>, dim3(blocks), dim3(threads), 0, s, (const double *)buf, n, bad);
+}
+
+// ---------------------------------------------------------------------------
 // stage API: one complex multiply(-add) pass in the reference's operation order
 // ---------------------------------------------------------------------------
 // separately rounded multiply / add: the pragma strips the `contract` flag the

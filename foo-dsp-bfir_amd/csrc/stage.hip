@@ -176,15 +176,33 @@ extern "C" int bfir_convolver_mixnscale(bfir_convolver *c, void *const *input_cb
                                         const double *scales, int n_bufs, int mixmode)
 {
     if (!c || !input_cbufs || !output_cbuf || !scales) return BFIR_ERR_ARG;
-    // the engine only ever mixes one buffer (brutefir.cpp:273-277, 303-307)
-    if (n_bufs != 1 || (mixmode != BFIR_MIXMODE_INPUT && mixmode != BFIR_MIXMODE_OUTPUT)) {
+    // INPUT_ADD is declared (fftw_convolver.hpp:15) but mixnscale has no case for it (:1421-1424)
+    if (n_bufs < 1 || n_bufs > BFIR_MAX_MIX || (mixmode != BFIR_MIXMODE_INPUT && mixmode != BFIR_MIXMODE_OUTPUT)) {
         bfir_logf("Invalid mixmode: %d.\n", mixmode);
         return BFIR_ERR_UNSUPPORTED;
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->d[0], input_cbufs[0], cb(c), hipMemcpyHostToDevice, c->stream));
-    launch_reorder(c->d[0], c->d[1], c->N, scales[0], mixmode == BFIR_MIXMODE_INPUT, c->s, c->stream);
-    HIP_TRY(hipMemcpyAsync(output_cbuf, c->d[1], cb(c), hipMemcpyDeviceToHost, c->stream));
+    if (n_bufs == 1) {   // the engine only ever mixes one buffer (brutefir.cpp:273-277, 303-307)
+        HIP_TRY(hipMemcpyAsync(c->d[0], input_cbufs[0], cb(c), hipMemcpyHostToDevice, c->stream));
+        launch_reorder(c->d[0], c->d[1], c->N, scales[0], mixmode == BFIR_MIXMODE_INPUT, c->s, c->stream);
+        HIP_TRY(hipMemcpyAsync(output_cbuf, c->d[1], cb(c), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return BFIR_OK;
+    }
+    // mixing matrix row: out = sum_i in_i * scale_i (:908-1156, :1187-1419)
+    int rc = need_raw(c, (size_t)(n_bufs + 1) * cb(c));
+    if (rc != BFIR_OK) return rc;
+    MixArgs m;
+    m.n = n_bufs;
+    for (int i = 0; i < n_bufs; i++) {
+        if (!input_cbufs[i]) return BFIR_ERR_ARG;
+        m.in[i] = (char *)c->d_raw + (size_t)i * cb(c);
+        m.scale[i] = scales[i];
+        HIP_TRY(hipMemcpyAsync((void *)m.in[i], input_cbufs[i], cb(c), hipMemcpyHostToDevice, c->stream));
+    }
+    void *d_out = (char *)c->d_raw + (size_t)n_bufs * cb(c);
+    launch_reorder_n(m, d_out, c->N, mixmode == BFIR_MIXMODE_INPUT, c->s, c->stream);
+    HIP_TRY(hipMemcpyAsync(output_cbuf, d_out, cb(c), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BFIR_OK;
 }
@@ -291,4 +309,124 @@ extern "C" void *bfir_convolver_coeffs2cbuf(bfir_convolver *c, const void *coeff
         return nullptr;
     }
     return dest;
+}
+
+// ---------------------------------------------------------------------------
+// the methods of the class nothing in the tree calls
+// ---------------------------------------------------------------------------
+// convolver_runtime_coeffs2cbuf (fftw_convolver.cpp:539-567): n_fft2 taps, scale 1, into dest
+extern "C" int bfir_convolver_runtime_coeffs2cbuf(bfir_convolver *c, const void *src, void *dest)
+{
+    if (!c || !src || !dest) return BFIR_ERR_ARG;
+    return bfir_convolver_coeffs2cbuf(c, src, c->L, 1.0, dest) ? BFIR_OK : BFIR_ERR_COEFF;
+}
+
+// convolver_dirac_convolve / _inplace (:323-348)
+extern "C" int bfir_convolver_dirac_convolve(bfir_convolver *c, const void *input_cbuf, void *output_cbuf)
+{
+    if (!c || !input_cbuf || !output_cbuf) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d[0], input_cbuf, cb(c), hipMemcpyHostToDevice, c->stream));
+    launch_dirac(c->d[0], c->d[1], c->N, c->s, c->stream);
+    HIP_TRY(hipMemcpyAsync(output_cbuf, c->d[1], cb(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFIR_OK;
+}
+
+extern "C" int bfir_convolver_dirac_convolve_inplace(bfir_convolver *c, void *cbuf)
+{
+    return bfir_convolver_dirac_convolve(c, cbuf, cbuf);
+}
+
+// half-complex spectrum in d[src] -> time domain in d[dst] (HC2R, all N samples), via d[tmp]
+static void hc2r_dev(bfir_convolver *c, int src, int tmp, void *dst)
+{
+    launch_reorder(c->d[src], c->d[tmp], c->N, 1.0, 1, c->s, c->stream);
+    InvArgs a;
+    a.src = c->d[tmp]; a.src_ch_stride = 0; a.dst = dst; a.dst_ch_stride = 0;
+    a.n_t = 1; a.n_ch = 1; a.in_scale = 1.0; a.full_output = 1;
+    launch_inv(c->plan, a, c->stream);
+}
+
+// time domain at `src` (N samples) -> half-complex spectrum in d[dst], via d[tmp]
+static void r2hc_dev(bfir_convolver *c, const void *src, int tmp, int dst)
+{
+    FwdArgs a;
+    a.prev = src; a.prev_ch_stride = 0;
+    a.src = (const char *)src + (size_t)c->L * c->s; a.src_ch_stride = 0;
+    a.dst = c->d[tmp]; a.dst_ch_stride = 0;
+    a.ring = 1; a.base_slot = 0; a.n_t = 1; a.n_ch = 1;
+    a.load_scale = 1.0; a.out_scale = 1.0; a.zero_first_half = 0;
+    launch_fwd(c->plan, a, c->stream);
+    launch_reorder(c->d[tmp], c->d[dst], c->N, 1.0, 0, c->s, c->stream);
+}
+
+// convolver_convolve_eval (:377-403).  buffer_cbuf: 1.5 cbufs, cleared before the first call.
+extern "C" int bfir_convolver_convolve_eval(bfir_convolver *c, const void *input_cbuf, void *buffer_cbuf,
+                                            void *output_cbuf)
+{
+    if (!c || !input_cbuf || !buffer_cbuf || !output_cbuf) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t half = (size_t)c->L * c->s;
+    int rc = need_raw(c, 3 * half);
+    if (rc != BFIR_OK) return rc;
+    char *dbuf = (char *)c->d_raw;                                   // the 1.5-cbuf work buffer on the device
+    HIP_TRY(hipMemcpyAsync(dbuf, buffer_cbuf, half, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d[0], input_cbuf, cb(c), hipMemcpyHostToDevice, c->stream));
+    hc2r_dev(c, 0, 1, dbuf + half);                                  // HC2R into buffer[n_fft2 ..]
+    r2hc_dev(c, dbuf, 1, 2);                                         // R2HC of buffer[0 .. n_fft)
+    HIP_TRY(hipMemcpyAsync(output_cbuf, c->d[2], cb(c), hipMemcpyDeviceToHost, c->stream));
+    // the reference leaves [new first half | rest of the HC2R output] in the buffer (:401-402)
+    HIP_TRY(hipMemcpyAsync(buffer_cbuf, dbuf + half, half, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync((char *)buffer_cbuf + half, dbuf + half, 2 * half, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFIR_OK;
+}
+
+// convolver_crossfade_inplace (:275-321).  buffer_cbuf: 1.5 cbufs (the double path reads
+// buffer[n_fft ..], exactly as the reference does).
+extern "C" int bfir_convolver_crossfade_inplace(bfir_convolver *c, void *input_cbuf, void *crossfade_cbuf,
+                                                void *buffer_cbuf)
+{
+    if (!c || !input_cbuf || !crossfade_cbuf || !buffer_cbuf) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t half = (size_t)c->L * c->s;
+    int rc = need_raw(c, 5 * half);
+    if (rc != BFIR_OK) return rc;
+    char *d_cf = (char *)c->d_raw, *d_buf = d_cf + 2 * half;          // crossfade (1 cbuf), buffer (1.5 cbufs)
+    HIP_TRY(hipMemcpyAsync(d_buf + 2 * half, (char *)buffer_cbuf + 2 * half, half, hipMemcpyHostToDevice, c->stream));
+    // OUTPUT reorder + HC2R of the crossfade spectrum, then of the input spectrum (:289-294)
+    HIP_TRY(hipMemcpyAsync(c->d[0], crossfade_cbuf, cb(c), hipMemcpyHostToDevice, c->stream));
+    launch_reorder(c->d[0], c->d[1], c->N, 1.0, 0, c->s, c->stream);
+    hc2r_dev(c, 1, 2, d_cf);
+    HIP_TRY(hipMemcpyAsync(c->d[0], input_cbuf, cb(c), hipMemcpyHostToDevice, c->stream));
+    launch_reorder(c->d[0], c->d[1], c->N, 1.0, 0, c->s, c->stream);
+    hc2r_dev(c, 1, 2, d_buf);
+    launch_crossfade_blend(d_cf, d_buf, d_buf + 2 * half, c->L, c->s, c->stream);   // :296-315
+    r2hc_dev(c, d_buf, 1, 2);                                                        // :317
+    launch_reorder(c->d[2], c->d[0], c->N, 1.0 / (double)c->N, 1, c->s, c->stream);  // :318-320
+    HIP_TRY(hipMemcpyAsync(input_cbuf, c->d[0], cb(c), hipMemcpyDeviceToHost, c->stream));
+    // what the reference leaves behind in its scratch arguments
+    HIP_TRY(hipMemcpyAsync(crossfade_cbuf, d_cf, cb(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(buffer_cbuf, c->d[2], cb(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFIR_OK;
+}
+
+// convolver_verify_cbuf (:569-602): 1 when every value is finite, 0 otherwise
+extern "C" int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs, int n_cbufs)
+{
+    if (!c || !cbufs || n_cbufs < 0) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+    for (int n = 0; n < n_cbufs; n++) {
+        if (!cbufs[n]) return BFIR_ERR_ARG;
+        HIP_TRY(hipMemcpyAsync(c->d[0], cbufs[n], cb(c), hipMemcpyHostToDevice, c->stream));
+        launch_check_finite(c->d[0], c->N, c->s, c->d_bad, c->stream);
+    }
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bad) bfir_logf("NaN or Inf value among coefficients.\n");
+    return bad ? 0 : 1;
 }

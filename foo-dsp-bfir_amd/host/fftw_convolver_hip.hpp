@@ -14,8 +14,8 @@
 //    brutefir.cpp:844-854).
 //  * create_fft_plan returns an opaque token, not an FFTW plan; equalizer.cpp,
 //    which executes the plan with FFTW directly, is outside this path.
-//  * methods nothing in the tree calls (crossfade, dirac, eval, td_*, N-input
-//    mixnscale) report "unsupported" through the log callback.
+//  * convolver_debug_dump_cbuf (text-file dump) and the convolver_td_* family (used only
+//    by the dead `delay` class) are not provided.
 #pragma once
 #include <stdexcept>
 
@@ -89,6 +89,31 @@ public:
     {
         return bfir_convolver_coeffs2cbuf(m_c, coeffs, n_coeffs, scale, optional_dest);
     }
+    // ---- declared by the reference, called by nothing in its tree ----
+    // :275-321.  buffer_cbuf: 1.5 cbufs.
+    void convolver_crossfade_inplace(void *input_cbuf, void *crossfade_cbuf, void *buffer_cbuf)
+    {
+        m_last = bfir_convolver_crossfade_inplace(m_c, input_cbuf, crossfade_cbuf, buffer_cbuf);
+    }
+    // :323-348
+    void convolver_dirac_convolve(void *input_cbuf, void *output_cbuf)
+    {
+        m_last = bfir_convolver_dirac_convolve(m_c, input_cbuf, output_cbuf);
+    }
+    void convolver_dirac_convolve_inplace(void *cbuf) { m_last = bfir_convolver_dirac_convolve_inplace(m_c, cbuf); }
+    // :377-403.  buffer_cbuf: 1.5 cbufs, cleared before the first call, kept afterwards.
+    void convolver_convolve_eval(void *input_cbuf, void *buffer_cbuf, void *output_cbuf)
+    {
+        m_last = bfir_convolver_convolve_eval(m_c, input_cbuf, buffer_cbuf, output_cbuf);
+    }
+    // :539-567
+    void convolver_runtime_coeffs2cbuf(void *src, void *dest)
+    {
+        m_last = bfir_convolver_runtime_coeffs2cbuf(m_c, src, dest);
+    }
+    // :569-602
+    bool convolver_verify_cbuf(void *cbufs[], int n_cbufs) { return bfir_convolver_verify_cbuf(m_c, cbufs, n_cbufs) == 1; }
+
     // :653-695: plans are device tables owned by the convolver; the token is only good
     // for passing back to destroy_fft_plan.
     void *create_fft_plan(int, int, int) { return m_c; }

@@ -203,6 +203,22 @@ int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void *outbuf,
  * NULL on a NaN/Inf tap. */
 void *bfir_convolver_coeffs2cbuf(bfir_convolver *c, const void *coeffs, int n_coeffs, double scale,
                                  void *optional_dest);
+/* Methods of the class that nothing in the reference tree calls.
+ * convolver_mixnscale above takes any n_bufs <= 32 (mixing matrix rows,
+ * :908-1156, :1187-1419). */
+/* convolver_runtime_coeffs2cbuf (:539-567): n_fft2 taps at src -> spectrum at dest */
+int bfir_convolver_runtime_coeffs2cbuf(bfir_convolver *c, const void *src, void *dest);
+/* convolver_dirac_convolve / _inplace (:323-348) */
+int bfir_convolver_dirac_convolve(bfir_convolver *c, const void *input_cbuf, void *output_cbuf);
+int bfir_convolver_dirac_convolve_inplace(bfir_convolver *c, void *cbuf);
+/* convolver_convolve_eval (:377-403); buffer_cbuf is 1.5 cbufs, zeroed before the first call */
+int bfir_convolver_convolve_eval(bfir_convolver *c, const void *input_cbuf, void *buffer_cbuf,
+                                 void *output_cbuf);
+/* convolver_crossfade_inplace (:275-321); buffer_cbuf is 1.5 cbufs */
+int bfir_convolver_crossfade_inplace(bfir_convolver *c, void *input_cbuf, void *crossfade_cbuf,
+                                     void *buffer_cbuf);
+/* convolver_verify_cbuf (:569-602): 1 = all finite, 0 = NaN/Inf found, < 0 = error */
+int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs, int n_cbufs);
 void *bfir_aligned_malloc(size_t size, size_t alignment);
 void bfir_aligned_free(void *p);
 

@@ -48,6 +48,45 @@ double orc_fmt_max(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_s
 #undef REAL
 #undef SUF
 
+/* convolver_crossfade_inplace (brutefir/fftw_convolver.cpp:275-321): both spectra
+ * to the time domain, linear cross-fade over the first n_fft2 samples, back to a
+ * spectrum scaled 1/n_fft.  The expressions below are the reference's, so the
+ * float path promotes through double exactly as it does (1.0 is a double literal).
+ * The double path blends buffer[0..) with buffer[n_fft..) -- NOT with the
+ * transformed crossfade buffer -- exactly as written there (:311-313); buffer
+ * therefore holds 1.5 n_fft reals. */
+void orc_crossfade_inplace_f(int n_fft, float *input, float *crossfade, float *buffer)
+{
+    const int n_fft2 = n_fft / 2;
+    float f;
+    int n;
+    orc_mixnscale_f(n_fft, crossfade, buffer, 1.0, ORC_MIXMODE_OUTPUT);
+    orc_hc2r_f(n_fft, buffer, crossfade);
+    orc_mixnscale_f(n_fft, input, buffer, 1.0, ORC_MIXMODE_OUTPUT);
+    orc_hc2r_f(n_fft, buffer, buffer);
+    f = 1.0 / (float)(n_fft2 - 1);
+    for (n = 0; n < n_fft2; n++)
+        buffer[n] = crossfade[n] * (1.0 - f * (float)n) + buffer[n] * f * (float)n;
+    orc_r2hc_f(n_fft, buffer, buffer);
+    orc_mixnscale_f(n_fft, buffer, input, 1.0 / (double)n_fft, ORC_MIXMODE_INPUT);
+}
+
+void orc_crossfade_inplace_d(int n_fft, double *input, double *crossfade, double *buffer)
+{
+    const int n_fft2 = n_fft / 2;
+    double *buf1 = buffer, *buf2 = buffer + n_fft, d;
+    int n;
+    orc_mixnscale_d(n_fft, crossfade, buffer, 1.0, ORC_MIXMODE_OUTPUT);
+    orc_hc2r_d(n_fft, buffer, crossfade);
+    orc_mixnscale_d(n_fft, input, buffer, 1.0, ORC_MIXMODE_OUTPUT);
+    orc_hc2r_d(n_fft, buffer, buffer);
+    d = 1.0 / (double)(n_fft2 - 1);
+    for (n = 0; n < n_fft2; n++)
+        buf1[n] = buf1[n] * (1.0 - d * (double)n) + buf2[n] * d * (double)n;
+    orc_r2hc_d(n_fft, buffer, buffer);
+    orc_mixnscale_d(n_fft, buffer, input, 1.0 / (double)n_fft, ORC_MIXMODE_INPUT);
+}
+
 #define ORC_MAXCH 8 /* BF_MAXCHANNELS, brutefir/global.h:21 */
 
 /* State of one brutefir instance (brutefir/brutefir.hpp:96-127), kept as

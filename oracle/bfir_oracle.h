@@ -108,6 +108,20 @@ void orc_raw2real_fmt_d(double *real, const void *raw, int fmt, int spacing, int
 void orc_real2raw_fmt_f(void *raw, const float *real, int fmt, int spacing, int n, orc_overflow_t *of);
 void orc_real2raw_fmt_d(void *raw, const double *real, int fmt, int spacing, int n, orc_overflow_t *of);
 
+/* ---- boundary features nothing in the tree calls ---- */
+/* mixnscale with n_bufs >= 1 (fftw_convolver.cpp:908-1156, 1187-1419). */
+void orc_mixnscale_n_f(int n_fft, const float *const *ins, float *out, const double *scales, int n_bufs, int mixmode);
+void orc_mixnscale_n_d(int n_fft, const double *const *ins, double *out, const double *scales, int n_bufs, int mixmode);
+/* dirac_convolve (:323-348, 1527-1556, 2222-2251); in == out allowed. */
+void orc_dirac_convolve_f(int n_fft, const float *in, float *out);
+void orc_dirac_convolve_d(int n_fft, const double *in, double *out);
+/* convolver_convolve_eval (:377-403); buffer: 1.5 n_fft reals, kept between calls. */
+void orc_convolve_eval_f(int n_fft, const float *in, float *buffer, float *out);
+void orc_convolve_eval_d(int n_fft, const double *in, double *buffer, double *out);
+/* convolver_crossfade_inplace (:275-321); buffer: 1.5 n_fft reals. */
+void orc_crossfade_inplace_f(int n_fft, float *input, float *crossfade, float *buffer);
+void orc_crossfade_inplace_d(int n_fft, double *input, double *crossfade, double *buffer);
+
 /* ---- engine level: brutefir::brutefir / set_coeff / run / reset ---- */
 typedef struct orc_engine orc_engine;
 

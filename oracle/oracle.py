@@ -76,6 +76,12 @@ def lib():
             "orc_real2raw_fmt_f": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
             "orc_real2raw_fmt_d": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
             "orc_fmt_in_scale": (cd, [ci]), "orc_fmt_out_scale": (cd, [ci]), "orc_fmt_max": (cd, [ci]),
+            "orc_mixnscale_n_f": (None, [ci, C.POINTER(vp), vp, C.POINTER(cd), ci, ci]),
+            "orc_mixnscale_n_d": (None, [ci, C.POINTER(vp), vp, C.POINTER(cd), ci, ci]),
+            "orc_dirac_convolve_f": (None, [ci, vp, vp]), "orc_dirac_convolve_d": (None, [ci, vp, vp]),
+            "orc_convolve_eval_f": (None, [ci, vp, vp, vp]), "orc_convolve_eval_d": (None, [ci, vp, vp, vp]),
+            "orc_crossfade_inplace_f": (None, [ci, vp, vp, vp]),
+            "orc_crossfade_inplace_d": (None, [ci, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -202,6 +208,35 @@ def real2raw(real, raw, channel, of):
     base = raw.ctypes.data + channel * raw.itemsize
     getattr(lib(), "orc_real2raw" + _suf(real.dtype))(C.c_void_p(base), _p(real), raw.itemsize,
                                                       raw.shape[1], real.size, C.byref(of))
+
+
+def mixnscale_n(ins, scales, mixmode):
+    ins = [np.ascontiguousarray(a) for a in ins]
+    out = np.zeros_like(ins[0])
+    ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
+    sc = (C.c_double * len(ins))(*[float(v) for v in scales])
+    getattr(lib(), "orc_mixnscale_n" + _suf(out.dtype))(out.size, ptrs, _p(out), sc, len(ins), mixmode)
+    return out
+
+
+def dirac_convolve(x):
+    x = np.ascontiguousarray(x)
+    out = np.empty_like(x)
+    getattr(lib(), "orc_dirac_convolve" + _suf(x.dtype))(x.size, _p(x), _p(out))
+    return out
+
+
+def convolve_eval(x, buffer):
+    """Returns the output; `buffer` (1.5 n_fft reals) is updated in place."""
+    x = np.ascontiguousarray(x)
+    out = np.empty_like(x)
+    getattr(lib(), "orc_convolve_eval" + _suf(x.dtype))(x.size, _p(x), _p(buffer), _p(out))
+    return out
+
+
+def crossfade_inplace(inp, crossfade, buffer):
+    """All three arrays are updated in place (as the reference's are)."""
+    getattr(lib(), "orc_crossfade_inplace" + _suf(inp.dtype))(inp.size, _p(inp), _p(crossfade), _p(buffer))
 
 
 def raw2real_fmt(raw, channel, fmt, realsize):

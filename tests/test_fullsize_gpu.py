@@ -55,3 +55,28 @@ def test_fullsize_properties(orc, bfir, name, s, C, taps, L, nb):
     yd = run(x1, coeffs=[d2] * C)
     lag = (B - 1) * L + 3
     assert rel_err(yd[lag:], x1[:-lag]) <= tol and np.abs(yd[:lag]).max() <= tol
+
+
+def test_cfg4_batch_of_32_stereo_engines_fullsize(orc, bfir):
+    """BASELINE configs[3], one GPU's share: 32 independent stereo engines, 65536 taps,
+    L = 4096 (B = 16), sharing launches.  Engines must not leak into each other, results must
+    equal the same engines run alone (bit for bit) and the oracle on the leading blocks."""
+    s, C, taps, L, E, nb = 4, 2, 65536, 4096, 32, 40
+    B = taps // L
+    rng = np.random.default_rng(44)
+    hs = [orc.synth_ir(rng, C, taps, np.float32) for _ in range(E)]
+    xs = np.stack([orc.synth_audio(rng, nb * L, C, np.float32) for _ in range(E)])
+    xs[7] = 0.0                                          # a silent stream must stay silent
+    batch = bfir.Brutefir(L, B, s, C, n_engines=E)
+    batch.set_chunk(16)
+    for e in range(E):
+        assert batch.set_coeff(hs[e], engine_index=e) == 0
+    rc, y = batch.run(xs)
+    assert rc == 0 and np.all(y[7] == 0.0)
+    for e in (0, 13, 31):
+        one = bfir.Brutefir(L, B, s, C); one.set_chunk(16); one.set_coeff(hs[e])
+        assert np.array_equal(one.run(xs[e])[1], y[e])
+        ref = orc.Engine(L, B, s, C); ref.set_coeff(hs[e])
+        k = 5
+        assert rel_err(y[e][:k * L], ref.run(xs[e][:k * L])[1]) <= TOL[s]
+    assert all(batch.overflow(c).n_overflows == 0 for c in range(E * C))

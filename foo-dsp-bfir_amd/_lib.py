@@ -78,6 +78,11 @@ SIGNATURES = {
     "bfir_convolver_convolve_eval": (_ci, [_vp, _vp, _vp, _vp]),
     "bfir_convolver_crossfade_inplace": (_ci, [_vp, _vp, _vp, _vp]),
     "bfir_convolver_verify_cbuf": (_ci, [_vp, C.POINTER(_vp), _ci]),
+    "bfir_fft_plan_create": (_vp, [_ci, _ci, _ci, _ci, _ci, _pi]),
+    "bfir_fft_plan_destroy": (None, [_vp]),
+    "bfir_fft_plan_execute": (_ci, [_vp, _vp, _vp]),
+    "bfir_fft_plan_length": (_cl, [_vp]),
+    "bfir_equalizer_render": (_ci, [_vp, _ci, C.POINTER(_cd), C.POINTER(_cd), C.POINTER(_cd), _vp]),
     "bfir_aligned_malloc": (_vp, [C.c_size_t, C.c_size_t]),
     "bfir_aligned_free": (None, [_vp]),
 }

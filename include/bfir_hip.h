@@ -219,6 +219,27 @@ int bfir_convolver_crossfade_inplace(bfir_convolver *c, void *input_cbuf, void *
                                      void *buffer_cbuf);
 /* convolver_verify_cbuf (:569-602): 1 = all finite, 0 = NaN/Inf found, < 0 = error */
 int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs, int n_cbufs);
+/* ------------------------------------------------------------------ */
+/* FFT plans of any power-of-two size and the equalizer render          */
+/*                                                     */
+/* ------------------------------------------------------------------ */
+typedef struct bfir_fft_plan bfir_fft_plan;
+
+/* fftw_convolver::create_fft_plan(order, invert, inplace) (fftw_convolver.cpp:653-675):
+ * FFTW_R2HC (invert 0) or FFTW_HC2R (invert 1) of 2^order reals, 5 <= order <= 25.
+ * Sizes beyond one workgroup's LDS run as a four-step FFT. */
+bfir_fft_plan *bfir_fft_plan_create(int order, int invert, int inplace, int realsize, int device, int *err);
+void bfir_fft_plan_destroy(bfir_fft_plan *p);
+/* fftw[f]_execute_r2r(plan, in, out) on host buffers of 2^order reals; in == out allowed
+ * (replaces the direct FFTW calls at equalizer.cpp:262, 357). */
+int bfir_fft_plan_execute(bfir_fft_plan *p, const void *in, void *out);
+long bfir_fft_plan_length(const bfir_fft_plan *p);
+/* equalizer::render_f / render_d (equalizer.cpp:211-299, 301-394): band tables as
+ * equalizer::generate leaves them (:113-118) -> taps/2-sample impulse response in ir_out.
+ * ifftplan: an HC2R plan of `taps` reals. */
+int bfir_equalizer_render(bfir_fft_plan *ifftplan, int band_count, const double *freq, const double *mag,
+                          const double *phase, void *ir_out);
+
 void *bfir_aligned_malloc(size_t size, size_t alignment);
 void bfir_aligned_free(void *p);
 

@@ -87,6 +87,105 @@ void orc_crossfade_inplace_d(int n_fft, double *input, double *crossfade, double
     orc_mixnscale_d(n_fft, buffer, input, 1.0 / (double)n_fft, ORC_MIXMODE_INPUT);
 }
 
+/* ------------------------------------------------------------------ */
+/* equalizer: brutefir/equalizer.cpp                  */
+/* ------------------------------------------------------------------ */
+#define ORC_ISO_BANDS 31
+static const double orc_iso_bands[ORC_ISO_BANDS] = { /* brutefir/equalizer.hpp:17-50 */
+    20, 25, 31.5, 40, 50, 63, 80, 100, 125, 160, 200, 250, 315, 400, 500, 630, 800, 1000, 1250, 1600, 2000,
+    2500, 3150, 4000, 5000, 6300, 8000, 10000, 12500, 16000, 20000};
+
+/* equalizer::equalizer (:29-69) + equalizer::generate up to the render call (:86-118):
+ * place the caller's bands on the ISO grid (plus 0 Hz and Nyquist), convert to
+ * normalised frequency, linear magnitude and phase / (180 pi).  Tables of 33. */
+int orc_equalizer_bands(int sampling_rate, int n_bands, const double *freq, const double *mag,
+                        const double *phase, double *ofreq, double *omag, double *ophase)
+{
+    const int count = ORC_ISO_BANDS + 2;
+    int n, i;
+    if (n_bands > ORC_ISO_BANDS) return -1;
+    memset(omag, 0, sizeof(double) * count);
+    memset(ophase, 0, sizeof(double) * count);
+    ofreq[0] = 0.0;
+    ofreq[count - 1] = (double)sampling_rate / 2.0;
+    for (n = 0; n < ORC_ISO_BANDS; n++) ofreq[n + 1] = orc_iso_bands[n];
+    for (n = 0, i = 0; n < n_bands; n++) {
+        while (freq[n] > ofreq[i]) i++;
+        omag[i] = mag[n];
+        ophase[i] = phase[n];
+        i++;
+    }
+    omag[0] = omag[1];
+    omag[count - 1] = omag[count - 2];
+    for (n = 0; n < count; n++) {
+        ofreq[n] /= (double)sampling_rate;
+        omag[n] = pow(10, omag[n] / 20);
+        ophase[n] /= (180 * M_PI);
+    }
+    return count;
+}
+
+static float orc_cosine_int_f(float mag1, float mag2, float freq1, float freq2, float curfreq)
+{   /* :182-192 */
+    return (mag1 - mag2) * 0.5 * cos(M_PI * (curfreq - freq1) / (freq2 - freq1)) + (mag1 + mag2) * 0.5;
+}
+static double orc_cosine_int_d(double mag1, double mag2, double freq1, double freq2, double curfreq)
+{   /* :194-204 */
+    return (mag1 - mag2) * 0.5 * cos(M_PI * (curfreq - freq1) / (freq2 - freq1)) + (mag1 + mag2) * 0.5;
+}
+
+/* equalizer::render_f (:211-299): ir receives taps/2 floats (the upper half of the HC2R output). */
+void orc_equalizer_render_f(int taps, int band_count, const double *freq, const double *mag, const double *phase,
+                            float *ir)
+{
+    float m, rad, curfreq, scale, divtaps, tapspi;
+    float eqmag[64], eqfreq[64], eqphase[64];
+    float *rbuf = (float *)malloc(sizeof(float) * (size_t)taps);
+    int n, i;
+    for (n = 0; n < band_count; n++) { eqmag[n] = (float)mag[n]; eqfreq[n] = (float)freq[n]; eqphase[n] = (float)phase[n]; }
+    scale = 1.0 / (float)taps;
+    divtaps = 1.0 / (float)taps;
+    tapspi = -(float)taps * M_PI;
+    rbuf[0] = eqmag[0] * scale;
+    for (n = 1, i = 0; n < taps >> 1; n++) {
+        curfreq = (float)n * divtaps;
+        while (curfreq > eqfreq[i + 1]) i++;
+        m = orc_cosine_int_f(eqmag[i], eqmag[i + 1], eqfreq[i], eqfreq[i + 1], curfreq) * scale;
+        rad = tapspi * curfreq + orc_cosine_int_f(eqphase[i], eqphase[i + 1], eqfreq[i], eqfreq[i + 1], curfreq);
+        rbuf[n] = cos(rad) * m;
+        rbuf[taps - n] = sin(rad) * m;
+    }
+    rbuf[taps >> 1] = eqmag[band_count - 1] * scale;
+    orc_hc2r_f(taps, rbuf, rbuf);
+    memcpy(ir, rbuf + (taps >> 1), sizeof(float) * (size_t)(taps >> 1));
+    free(rbuf);
+}
+
+/* equalizer::render_d (:301-394) */
+void orc_equalizer_render_d(int taps, int band_count, const double *freq, const double *mag, const double *phase,
+                            double *ir)
+{
+    double m, rad, curfreq, scale, divtaps, tapspi;
+    double *rbuf = (double *)malloc(sizeof(double) * (size_t)taps);
+    int n, i;
+    scale = 1.0 / (double)taps;
+    divtaps = 1.0 / (double)taps;
+    tapspi = -(double)taps * M_PI;
+    rbuf[0] = mag[0] * scale;
+    for (n = 1, i = 0; n < taps >> 1; n++) {
+        curfreq = (double)n * divtaps;
+        while (curfreq > freq[i + 1]) i++;
+        m = orc_cosine_int_d(mag[i], mag[i + 1], freq[i], freq[i + 1], curfreq) * scale;
+        rad = tapspi * curfreq + orc_cosine_int_d(phase[i], phase[i + 1], freq[i], freq[i + 1], curfreq);
+        rbuf[n] = cos(rad) * m;
+        rbuf[taps - n] = sin(rad) * m;
+    }
+    rbuf[taps >> 1] = mag[band_count - 1] * scale;
+    orc_hc2r_d(taps, rbuf, rbuf);
+    memcpy(ir, rbuf + (taps >> 1), sizeof(double) * (size_t)(taps >> 1));
+    free(rbuf);
+}
+
 #define ORC_MAXCH 8 /* BF_MAXCHANNELS, brutefir/global.h:21 */
 
 /* State of one brutefir instance (brutefir/brutefir.hpp:96-127), kept as

@@ -122,6 +122,16 @@ void orc_convolve_eval_d(int n_fft, const double *in, double *buffer, double *ou
 void orc_crossfade_inplace_f(int n_fft, float *input, float *crossfade, float *buffer);
 void orc_crossfade_inplace_d(int n_fft, double *input, double *crossfade, double *buffer);
 
+/* ---- equalizer: brutefir/equalizer.cpp ---- */
+/* ctor + generate() up to the render call (:29-118): 33-entry tables; returns 33 or -1 */
+int orc_equalizer_bands(int sampling_rate, int n_bands, const double *freq, const double *mag,
+                        const double *phase, double *ofreq, double *omag, double *ophase);
+/* render_f / render_d (:211-394): taps/2 samples into ir */
+void orc_equalizer_render_f(int taps, int band_count, const double *freq, const double *mag, const double *phase,
+                            float *ir);
+void orc_equalizer_render_d(int taps, int band_count, const double *freq, const double *mag, const double *phase,
+                            double *ir);
+
 /* ---- engine level: brutefir::brutefir / set_coeff / run / reset ---- */
 typedef struct orc_engine orc_engine;
 

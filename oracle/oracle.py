@@ -239,6 +239,28 @@ def crossfade_inplace(inp, crossfade, buffer):
     getattr(lib(), "orc_crossfade_inplace" + _suf(inp.dtype))(inp.size, _p(inp), _p(crossfade), _p(buffer))
 
 
+def equalizer_bands(sampling_rate, freq, mag, phase):
+    """equalizer ctor + generate() up to the render call: three 33-entry tables."""
+    f, m, p = (np.ascontiguousarray(a, dtype=np.float64) for a in (freq, mag, phase))
+    of, om, op = np.zeros(33), np.zeros(33), np.zeros(33)
+    L = lib()
+    L.orc_equalizer_bands.restype = C.c_int
+    L.orc_equalizer_bands.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
+    n = L.orc_equalizer_bands(sampling_rate, f.size, _p(f), _p(m), _p(p), _p(of), _p(om), _p(op))
+    assert n == 33
+    return of, om, op
+
+
+def equalizer_render(taps, freq, mag, phase, realsize):
+    ir = np.zeros(taps // 2, dtype=real_dtype(realsize))
+    fn = getattr(lib(), "orc_equalizer_render" + _suf(ir.dtype))
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(taps, len(freq), _p(np.ascontiguousarray(freq)), _p(np.ascontiguousarray(mag)),
+       _p(np.ascontiguousarray(phase)), _p(ir))
+    return ir
+
+
 def raw2real_fmt(raw, channel, fmt, realsize):
     """Channel `channel` of an interleaved raw buffer of any format -> working precision."""
     n, spacing = raw.shape[0], raw.shape[1]

@@ -14,6 +14,7 @@
 #include "../../foo-dsp-bfir_amd/host/brutefir_hip.hpp"
 #include "../../foo-dsp-bfir_amd/host/coeff_hip.hpp"
 #include "../../foo-dsp-bfir_amd/host/preprocessor_hip.hpp"
+#include "../../foo-dsp-bfir_amd/host/equalizer_hip.hpp"
 
 static int g_fail = 0;
 #define CHECK(cond, ...)                                        \
@@ -175,6 +176,22 @@ int main()
         double rest = 0;
         for (int i = 0; i < 500 * C; i++) if (i != 2 * C && i != 2 * C + 1) rest = std::max(rest, (double)std::fabs(o[i]));
         CHECK(rest < 1e-5, "cascade residue %g", rest);
+    }
+    // equalizer (equalizer.cpp): a flat 0 dB / zero-phase EQ renders to a unit impulse; cache file round trip
+    {
+        const char *dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        equalizer eq(1024, 8, 8, 2, 48000);
+        double f[1] = {1000.0}, m[1] = {0.0}, ph[1] = {0.0};
+        std::string path = eq.generate(1, f, m, ph, dir);
+        CHECK(!path.empty(), "equalizer render failed");
+        std::vector<uint8_t> frames; int ch = 0, nf = 0, rs = 0, rate = 0;
+        CHECK(wav_io::load_float(path, &frames, &ch, &nf, &rs, &rate), "cache WAV unreadable: %s", path.c_str());
+        CHECK(ch == 2 && nf == 4096 && rs == 8 && rate == 48000, "cache WAV header %d %d %d %d", ch, nf, rs, rate);
+        const double *d = (const double *)frames.data();
+        double rest = 0;
+        for (int i = 2; i < nf * ch; i++) rest = std::max(rest, std::fabs(d[i]));
+        CHECK(std::fabs(d[0] - 1.0) < 1e-9 && std::fabs(d[1] - 1.0) < 1e-9 && rest < 1e-9, "flat EQ impulse %g %g rest %g", d[0], d[1], rest);
+        remove(path.c_str());
     }
     printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
     return g_fail ? 1 : 0;

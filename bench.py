@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the timing reduction (nccl = RCCL; gloo lets several "
+                         "ranks rehearse the N > 1 path on one GPU together with --device)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     import torch
@@ -108,15 +112,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.device < 0 else args.device
+    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
+    red_dev = dev if args.dist_backend == "nccl" else None      # gloo reduces CPU tensors
 
     import foo_dsp_bfir_amd as bfir   # raises if the HIP library is missing
 
@@ -188,8 +193,8 @@ def main():
         eng.set_profiling(False)
 
     # the job's time is the slowest rank's; its work is the sum of every rank's units
-    elapsed = sharding.max_over_ranks(elapsed, dev)
-    total_samples = sharding.sum_over_ranks(n_eng * nb * L * C * args.steps, dev)
+    elapsed = sharding.max_over_ranks(elapsed, red_dev)
+    total_samples = sharding.sum_over_ranks(n_eng * nb * L * C * args.steps, red_dev)
     value = total_samples / elapsed / 1e6
 
     result = None

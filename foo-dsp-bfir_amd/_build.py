@@ -13,6 +13,7 @@ HEADERS = ["kernels.h", "fft_lds.h", os.path.join("..", "..", "include", "bfir_h
 # -fno-slp-vectorize: packing the FFT butterflies into v_pk_* costs more moves than it saves
 # (the MAC kernel asks for v_pk_fma_f32 explicitly).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-slp-vectorize"]
+FLAGS += os.environ.get("BFIR_EXTRA_FLAGS", "").split()   # tuning aid (A/B builds)
 
 
 def _stale(target, deps):

@@ -211,8 +211,13 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     // access pattern of the passes then is "per-thread base + compile-time offset"
     // (no per-element address arithmetic); all of them are bank-conflict free
     // except the stride-R writes of the first pass (2-way).
+#ifdef BFIR_FFT_XOR_SWIZZLE   // A/B switch: conflict-free XOR layout, exactly M elements (5 workgroups per CU at M = 4096 fp32)
+    static constexpr int LDS_ELEMS = M;
+    __device__ __forceinline__ static int phys(int i) { return i ^ ((i >> 4) & 15); }
+#else
     static constexpr int LDS_ELEMS = M + M / 32;
     __device__ __forceinline__ static int phys(int i) { return i + (i >> 5); }
+#endif
 
     // logical index held in register slot e before pass 0
     __device__ __forceinline__ static int in_index(int tid, int e)

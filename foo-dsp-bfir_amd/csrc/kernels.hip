@@ -441,19 +441,30 @@ __global__ __launch_bounds__(256, WPE) void k_mac(MacArgs a, int nbt, int nTT, i
 // ds_read_b128 of lane-contiguous data (conflict free).  One barrier per step.
 // Sums are formed in the same order with the same fma chain as k_mac, so the
 // two kernels give bit-identical results.
+// Native 4-wide vectors (not HIP's float4 struct): they are register-tuple aligned, so their
+// .lo / .hi halves feed v_pk_fma_f32 directly; scalarised struct members needed ~30 v_mov per step.
+typedef float v4f __attribute__((ext_vector_type(4)));
+// nhi = -hi, negated once per step by the caller (fma(-xi, hi, ar) == fma(xi, -hi, ar) exactly)
+__device__ __forceinline__ void cmac4(v4f &ar, v4f &ai, const v4f &xr, const v4f &xi, const v4f &hr, const v4f &hi,
+                                      const v4f &nhi)
+{
+    ar.lo = __builtin_elementwise_fma(xr.lo, hr.lo, ar.lo); ar.lo = __builtin_elementwise_fma(xi.lo, nhi.lo, ar.lo);
+    ar.hi = __builtin_elementwise_fma(xr.hi, hr.hi, ar.hi); ar.hi = __builtin_elementwise_fma(xi.hi, nhi.hi, ar.hi);
+    ai.lo = __builtin_elementwise_fma(xr.lo, hi.lo, ai.lo); ai.lo = __builtin_elementwise_fma(xi.lo, hr.lo, ai.lo);
+    ai.hi = __builtin_elementwise_fma(xr.hi, hi.hi, ai.hi); ai.hi = __builtin_elementwise_fma(xi.hi, hr.hi, ai.hi);
+}
+
 template <int D, bool DCNY>
-__device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[8], float (&dc)[8], float (&ny)[8],
-                                              float4 (&wr)[8], float4 (&wi)[8], float4 (*s_ring)[2][64],
-                                              float4 (*s_h)[2][64], const float4 *__restrict__ duty_base,
+__device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], float (&dc)[8], float (&ny)[8],
+                                              v4f (&wr)[8], v4f (&wi)[8], v4f (*s_ring)[2][64],
+                                              v4f (*s_h)[2][64], const v4f *__restrict__ duty_base,
                                               long duty_slot4, bool duty_is_h, int duty_plane, int nb, int ring,
                                               int sl_tb, int lane, int wv)
 {
     // duty: this wave fetches one plane (re or im) of H_s (waves 0,1) or of
     // X[tb - s] (waves 2,3) for every step s, D steps ahead of its use
-    // (a native vector type: HIP's float4 struct would be copied through private memory)
-    typedef float v4f __attribute__((ext_vector_type(4)));
     v4f q[D];
-    const v4f *__restrict__ dbase = (const v4f *)duty_base;
+    const v4f *__restrict__ dbase = duty_base;
     // The duty operand of step s sits at slot index dnext when s is the next one to fetch:
     // H waves walk up (clamped to the last partition), X waves walk down the ring with wrap.
     int dnext = duty_is_h ? 0 : sl_tb;
@@ -465,8 +476,8 @@ __device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[
 #define BFIR_DUTY_LOAD() dbase[dnext * duty_slot4 + duty_plane]
 #define BFIR_DUTY_STORE(s_, v_)                                                                     \
     do {                                                                                            \
-        float4 *dst_ = duty_is_h ? &s_h[(s_) & 1][duty_plane][lane] : &s_ring[(-(s_)) & 31][duty_plane][lane]; \
-        *(v4f *)dst_ = (v_);                                                                        \
+        v4f *dst_ = duty_is_h ? &s_h[(s_) & 1][duty_plane][lane] : &s_ring[(-(s_)) & 31][duty_plane][lane]; \
+        *dst_ = (v_);                                                                               \
     } while (0)
     // step 0: H_0 straight to LDS (X waves have no duty: the windows are loaded already)
     if (duty_is_h) { const v4f h0 = BFIR_DUTY_LOAD(); BFIR_DUTY_STORE(0, h0); }
@@ -478,7 +489,8 @@ __device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[
         for (int ii = 0; ii < 8; ii++) {
             const int i = i0 + ii;
             if (i < nb) {   // uniform over the workgroup
-                const float4 hr = s_h[ii & 1][0][lane], hi = s_h[ii & 1][1][lane];
+                const v4f hr = s_h[ii & 1][0][lane], hi = s_h[ii & 1][1][lane];
+                const v4f nhi = -hi;
                 if (i > 0) {
                     const int e = (8 * wv - i) & 31;             // ring entry holding X[tb + 8 wv - i]
                     wr[(8 - ii) % 8] = s_ring[e][0][lane]; wi[(8 - ii) % 8] = s_ring[e][1][lane];
@@ -486,7 +498,7 @@ __device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int idx = (j - ii + 8) % 8;            // window slot holding X[t0 + j - i]
-                    cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                    cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi, nhi);
                     if constexpr (DCNY) {
                         dc[j] = fma(wr[idx].x, hr.x, dc[j]);
                         ny[j] = fma(wi[idx].x, hi.x, ny[j]);
@@ -508,8 +520,8 @@ __device__ __forceinline__ void mac_lds_steps(float4 (&accr)[8], float4 (&acci)[
 template <int D>
 __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
 {
-    __shared__ __attribute__((aligned(16))) float4 s_ring[32][2][64];
-    __shared__ __attribute__((aligned(16))) float4 s_h[2][2][64];
+    __shared__ __attribute__((aligned(16))) v4f s_ring[32][2][64];
+    __shared__ __attribute__((aligned(16))) v4f s_h[2][2][64];
     static_assert(8 % D == 0, "prefetch depth must divide the unroll");
     const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
     const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
@@ -520,17 +532,17 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     const int g = bt * 64 + lane;
     const int tb = tq * 32, t0 = tb + 8 * wv;
     const long slot4 = a.N / 4;
-    const float4 *__restrict__ X = (const float4 *)((const float *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
-    const float4 *__restrict__ H = (const float4 *)((const float *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
+    const v4f *__restrict__ X = (const v4f *)((const float *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
+    const v4f *__restrict__ H = (const v4f *)((const float *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
     const int nb = a.nblk[gc];
     const int ring = a.ring;
     const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
 
-    float4 accr[8], acci[8], wr[8], wi[8];
+    v4f accr[8], acci[8], wr[8], wi[8];
     float dc[8], ny[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        accr[j] = float4{0, 0, 0, 0}; acci[j] = float4{0, 0, 0, 0};
+        accr[j] = v4f{0, 0, 0, 0}; acci[j] = v4f{0, 0, 0, 0};
         dc[j] = 0.f; ny[j] = 0.f;
         int sj = sl_tb + 8 * wv + j; if (sj >= ring) sj -= ring;
         wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
         const int t = t0 + j;
         if (t < a.n_t) {
             if (g == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
-            float4 *yo = (float4 *)(Y + (long)t * a.N) + 2 * g;
+            v4f *yo = (v4f *)(Y + (long)t * a.N) + 2 * g;
             yo[0] = accr[j]; yo[1] = acci[j];
         }
     }

@@ -98,6 +98,7 @@ struct bfir_engine {
     int want_chunk = 128;
     void *H = nullptr, *X = nullptr, *Y = nullptr, *tout = nullptr;
     void *tin[2] = {nullptr, nullptr};
+    void *Yb[2] = {nullptr, nullptr};      // product spectra, one buffer per chunk parity
     void *saved[2] = {nullptr, nullptr};   // [GC][L] each: materialised history blocks
     // first halves of the reference's input_timecbuf[n][0/1] (brutefir.cpp:255-260):
     // where the block each of them holds currently lives
@@ -110,10 +111,13 @@ struct bfir_engine {
     unsigned long long blockcounter = 0;
     unsigned long long chunk_seq = 0;       // chunks queued since creation
     int curbuf = 0;
-    // front (stage_in, fwd) runs on s_front, back (mac, inv, stage_out) on the
-    // caller's stream, so the front of chunk k+1 overlaps the back of chunk k
-    hipStream_t stream = nullptr, s_front = nullptr, s_in = nullptr, s_out = nullptr;
+    // front (stage_in, fwd) runs on s_front, the MAC on s_mac, the back (inv, stage_out) on the
+    // caller's stream, so fwd(k+1), mac(k) and inv/stage_out(k-1) are on the GPU together
+    hipStream_t stream = nullptr, s_front = nullptr, s_mac = nullptr, s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_entry = nullptr, ev_fwd[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr};
+    hipEvent_t ev_inv[2] = {nullptr, nullptr};
+    bool pipe3 = true;                     // BFIR_PIPE=2: MAC on the caller's stream (two-stage schedule)
+    bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
     void *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr};
@@ -150,7 +154,7 @@ static int materialise_history(bfir_engine *e)
 
 static void free_work(bfir_engine *e)
 {
-    void **bufs[] = {&e->X, &e->Y, &e->tin[0], &e->tin[1], &e->tout};
+    void **bufs[] = {&e->X, &e->Yb[0], &e->Yb[1], &e->tin[0], &e->tin[1], &e->tout};
     for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     for (int i = 0; i < 2; i++) {
         if (e->pin_in[i]) (void)hipHostFree(e->pin_in[i]);
@@ -172,9 +176,10 @@ static int alloc_work(bfir_engine *e, int chunk)
     // fwd of chunk k+1 may run while mac of chunk k still reads its B-1 older slots
     const int ring = 2 * chunk + e->B;
     if (e->X) { int rc = materialise_history(e); if (rc != BFIR_OK) return rc; }
-    void *X = nullptr, *Y = nullptr, *tin0 = nullptr, *tin1 = nullptr, *tout = nullptr;
+    void *X = nullptr, *Y0 = nullptr, *Y1 = nullptr, *tin0 = nullptr, *tin1 = nullptr, *tout = nullptr;
     HIP_TRY(hipMalloc(&X, (size_t)e->GC * ring * cb));
-    HIP_TRY(hipMalloc(&Y, (size_t)e->GC * chunk * cb));
+    HIP_TRY(hipMalloc(&Y0, (size_t)e->GC * chunk * cb));
+    HIP_TRY(hipMalloc(&Y1, (size_t)e->GC * chunk * cb));
     HIP_TRY(hipMalloc(&tin0, (size_t)e->GC * chunk * e->L * e->s));
     HIP_TRY(hipMalloc(&tin1, (size_t)e->GC * chunk * e->L * e->s));
     HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
@@ -191,7 +196,7 @@ static int alloc_work(bfir_engine *e, int chunk)
     }
     HIP_TRY(hipDeviceSynchronize());
     free_work(e);
-    e->X = X; e->Y = Y; e->tin[0] = tin0; e->tin[1] = tin1; e->tout = tout;
+    e->X = X; e->Yb[0] = Y0; e->Yb[1] = Y1; e->tin[0] = tin0; e->tin[1] = tin1; e->tout = tout;
     e->chunk = chunk; e->ring = ring;
     return BFIR_OK;
 }
@@ -236,15 +241,17 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     e->in_scale = fmt_info(in_format).isfloat ? 1.0 : 1.0 / fmt_full_scale(in_format);
     e->out_scale = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format);
     e->of_max = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format) - 1.0;
+    if (const char *pm = getenv("BFIR_PIPE")) { e->pipe3 = atoi(pm) >= 3; e->serial = atoi(pm) == 1; }
     e->nblk.assign(e->GC, 0);
     e->eng_init.assign(n_engines, 0);
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
     if (rc != 0) { *err = (rc == -1) ? BFIR_ERR_UNSUPPORTED : BFIR_ERR_HIP; delete e; return nullptr; }
     auto fail = [&](int code) { *err = code; bfir_engine_destroy(e); return (bfir_engine *)nullptr; };
-    hipStream_t *streams[] = {&e->stream, &e->s_front, &e->s_in, &e->s_out};
+    hipStream_t *streams[] = {&e->stream, &e->s_front, &e->s_mac, &e->s_in, &e->s_out};
     for (hipStream_t *st : streams)
         if (hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
     hipEvent_t *events[] = {&e->ev_entry, &e->ev_fwd[0], &e->ev_fwd[1], &e->ev_mac[0], &e->ev_mac[1],
+                            &e->ev_inv[0], &e->ev_inv[1],
                             &e->ev_h2d[0], &e->ev_h2d[1], &e->ev_comp[0], &e->ev_comp[1], &e->ev_d2h[0], &e->ev_d2h[1]};
     for (hipEvent_t *ev : events)
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return fail(BFIR_ERR_HIP);
@@ -290,10 +297,10 @@ extern "C" void bfir_engine_destroy(bfir_engine *e)
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto &sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    hipEvent_t events[] = {e->ev_entry, e->ev_fwd[0], e->ev_fwd[1], e->ev_mac[0], e->ev_mac[1],
+    hipEvent_t events[] = {e->ev_entry, e->ev_fwd[0], e->ev_fwd[1], e->ev_mac[0], e->ev_mac[1], e->ev_inv[0], e->ev_inv[1],
                            e->ev_h2d[0], e->ev_h2d[1], e->ev_comp[0], e->ev_comp[1], e->ev_d2h[0], e->ev_d2h[1]};
     for (hipEvent_t ev : events) if (ev) (void)hipEventDestroy(ev);
-    hipStream_t streams[] = {e->stream, e->s_front, e->s_in, e->s_out};
+    hipStream_t streams[] = {e->stream, e->s_front, e->s_mac, e->s_in, e->s_out};
     for (hipStream_t st : streams) if (st) (void)hipStreamDestroy(st);
     delete e;
 }
@@ -453,16 +460,19 @@ extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total
 }
 
 // ---------------------------------------------------------------------------
-// brutefir::run, chunked and software-pipelined over two streams
+// brutefir::run, chunked and software-pipelined over three streams
 // ---------------------------------------------------------------------------
 // Queue one chunk of tc blocks (frames frame_off .. of every engine's raw
 // buffer).  `st` is the caller's stream: the input must be ready on it when
 // this is called, and the output is complete on it when its work is.
 //   s_front : stage_in(k) -> fwd(k)                      (k = chunk sequence number)
-//   st      : mac(k) -> inv(k) -> stage_out(k)
+//   s_mac   : mac(k)                  waits fwd(k) and inv(k-2) (owner of Yb[k&1])
+//   st      : inv(k) -> stage_out(k)  waits mac(k)
 // fwd(k) writes delay-line slots that mac(k-2) may still read (ring = 2*chunk+B),
 // and stage_in(k) rewrites the time buffer fwd(k-2) read; both are ordered by
-// events / stream order, so front(k+1) overlaps back(k).
+// events / stream order.  So fwd(k+1), mac(k) and inv/stage_out(k-1) share the
+// GPU: none of the kernels saturates VALU or HBM alone (load-latency phases,
+// profiles/r01_phase_trace.txt), together they fill each other's gaps.
 static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
                      long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
 {
@@ -470,7 +480,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
     const long t_stride = (long)e->chunk * e->L;
     void *tin = e->tin[par];
     const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
-    hipStream_t sf = e->s_front;
+    hipStream_t sf = e->serial ? st : e->s_front;
 
     // the front only waits for the input, never for the back of the chunk before
     if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
@@ -500,28 +510,33 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         launch_fwd(e->plan, a, sf);
     }
     HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
-    HIP_TRY(hipStreamWaitEvent(st, e->ev_fwd[par], 0));
+    hipStream_t sm = e->pipe3 ? e->s_mac : st;
+    HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
+    if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    void *Y = e->Yb[e->pipe3 ? par : 0];
     {
-        ProfScope ps(e, BFIR_K_MAC, st);
+        ProfScope ps(e, BFIR_K_MAC, sm);
         MacArgs a;
         a.x = e->X; a.x_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
         a.h = e->H; a.h_ch_stride = (long)e->B * e->N;
         a.nblk = e->d_nblk;
-        a.y = e->Y; a.y_ch_stride = (long)e->chunk * e->N;
-        a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s;
-        launch_mac(a, st);
+        a.y = Y; a.y_ch_stride = (long)e->chunk * e->N;
+        a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s; a.B = e->B;
+        launch_mac(a, sm);
     }
-    HIP_TRY(hipEventRecord(e->ev_mac[par], st));
+    HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
+    if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
     {
         ProfScope ps(e, BFIR_K_INV, st);
         InvArgs a;
-        a.src = e->Y; a.src_ch_stride = (long)e->chunk * e->N;
+        a.src = Y; a.src_ch_stride = (long)e->chunk * e->N;
         a.dst = e->tout; a.dst_ch_stride = t_stride;
         a.n_t = tc; a.n_ch = e->GC;
         a.in_scale = e->out_scale;
         a.full_output = 0;
         launch_inv(e->plan, a, st);
     }
+    if (e->pipe3) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
     {
         ProfScope ps(e, BFIR_K_STAGE_OUT, st);
         StageOutArgs a;

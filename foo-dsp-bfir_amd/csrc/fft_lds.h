@@ -27,6 +27,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// -DBFIR_TRACE (tuning builds only, scripts/gpu_trace.sh): thread 0 of every workgroup stamps the
+// 100 MHz wall clock at phase boundaries into a device array read back by bfir_debug_read_trace.
+#ifdef BFIR_TRACE
+#define BFIR_TRACE_SLOTS 24
+#define BFIR_TRACE_WGS 4096
+static __device__ unsigned long long g_trace[3][BFIR_TRACE_WGS * BFIR_TRACE_SLOTS];
+#define BFIR_STAMP(kern, n)                                                                        \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
+        if (threadIdx.x == 0 && blockIdx.x < BFIR_TRACE_WGS)                                       \
+            g_trace[kern][blockIdx.x * BFIR_TRACE_SLOTS + (n)] = wall_clock64();                   \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define BFIR_STAMP(kern, n) do { } while (0)
+#endif
+
 namespace bfir {
 
 template <typename T> struct Vec2;
@@ -278,10 +296,13 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     // Full transform of the P register points (in_index order in, out_index order out).
     __device__ __forceinline__ static void run(T *re, T *im, V2 *lds, const V2 *__restrict__ tw, int tid)
     {
+        constexpr int TK = SIGN < 0 ? 0 : 1;   // trace array: forward / inverse
         butterflies<0>(re, im, tw, tid);
-        if constexpr (NP > 1) { exchange<0>(re, im, lds, tid); butterflies<1>(re, im, tw, tid); }
-        if constexpr (NP > 2) { exchange<1>(re, im, lds, tid); butterflies<2>(re, im, tw, tid); }
-        if constexpr (NP > 3) { exchange<2>(re, im, lds, tid); butterflies<3>(re, im, tw, tid); }
+        BFIR_STAMP(TK, 2);
+        if constexpr (NP > 1) { exchange<0>(re, im, lds, tid); BFIR_STAMP(TK, 3); butterflies<1>(re, im, tw, tid); BFIR_STAMP(TK, 4); }
+        if constexpr (NP > 2) { exchange<1>(re, im, lds, tid); BFIR_STAMP(TK, 5); butterflies<2>(re, im, tw, tid); BFIR_STAMP(TK, 6); }
+        if constexpr (NP > 3) { exchange<2>(re, im, lds, tid); BFIR_STAMP(TK, 7); butterflies<3>(re, im, tw, tid); BFIR_STAMP(TK, 8); }
+        (void)TK;
     }
 };
 

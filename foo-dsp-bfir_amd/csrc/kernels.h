@@ -95,6 +95,7 @@ struct MacArgs {
     const int *nblk;                               // device [n_ch]
     void *y; long y_ch_stride;                     // [gc][n_t][N]
     int n_t, n_ch, N, realsize;
+    int B = 0;                                     // partitions allocated per channel (max of nblk)
 };
 void launch_mac(const MacArgs &a, hipStream_t s);
 

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
     T *__restrict__ dst =
         (T *)a.dst + (long)gc * a.dst_ch_stride + (long)((a.base_slot + t) % a.ring) * N;
 
+    BFIR_STAMP(0, 0);
     // z[m] = x[2m] + i x[2m+1] over the window [previous block | this block]
     T re[P], im[P];
     const T ls = (T)a.load_scale;
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
         }
     }
 
+    BFIR_STAMP(0, 1);
     F::run(re, im, lds, tw, tid);
 
     // Z in natural order to LDS so every thread can fetch Z[M-k]
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
         if (k == 0) xi = re[e] - im[e];  // slot 4 carries Re X_{N/2}
         re[e] = xr * os; im[e] = xi * os;
     }
+    BFIR_STAMP(0, 9);
     __syncthreads();
     T *ldsr = (T *)lds;
 #pragma unroll
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
         const int idx = tid + j * NT;
         ((V4 *)dst)[idx] = ((const V4 *)ldsr)[idx];
     }
+    BFIR_STAMP(0, 10);
 }
 
 template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, const FwdArgs &a, int items, hipStream_t s)
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
     T *__restrict__ dst =
         (T *)a.dst + (long)gc * a.dst_ch_stride + (long)t * (a.full_output ? N : M);
 
+    BFIR_STAMP(1, 0);
     T *ldsr = (T *)lds;
 #pragma unroll
     for (int j = 0; j < P / 2; j++) {
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
         ((V4 *)ldsr)[idx] = ((const V4 *)src)[idx];
     }
     __syncthreads();
+    BFIR_STAMP(1, 9);
 
     // Z_k = (X_k + conj X_{M-k}) + i conj(W^k) (X_k - conj X_{M-k})
     T re[P], im[P];
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
         re[e] = ar - ti; im[e] = ai + tr;
     }
 
+    BFIR_STAMP(1, 1);
     F::run(re, im, lds, tw, tid);
 
 #pragma unroll
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
             *(V2 *)(dst + 2 * m) = v;
         }
     }
+    BFIR_STAMP(1, 10);
 }
 
 template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, const InvArgs &a, int items, hipStream_t s)
@@ -485,6 +493,7 @@ __device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], fl
     for (int d = 0; d < D; d++) { BFIR_DUTY_ADVANCE(); q[(1 + d) % D] = BFIR_DUTY_LOAD(); }   // steps 1 .. D
     __syncthreads();
     for (int i0 = 0; i0 < nb; i0 += 8) {
+        BFIR_STAMP(2, 2 + (i0 >> 3 < 6 ? i0 >> 3 : 6));
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
             const int i = i0 + ii;
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     const int ring = a.ring;
     const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
 
+    BFIR_STAMP(2, 0);
     v4f accr[8], acci[8], wr[8], wi[8];
     float dc[8], ny[8];
 #pragma unroll
@@ -548,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
         wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
         s_ring[8 * wv + j][0][lane] = wr[j]; s_ring[8 * wv + j][1][lane] = wi[j];
     }
+    BFIR_STAMP(2, 1);
     const bool duty_is_h = wv < 2;
     const int plane = wv & 1;
     if (bt == 0)
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     else
         mac_lds_steps<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
                                 nb, ring, sl_tb, lane, wv);
+    BFIR_STAMP(2, 9);
     float *__restrict__ Y = (float *)a.y + (long)gc * a.y_ch_stride;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -566,6 +578,180 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
             yo[0] = accr[j]; yo[1] = acci[j];
         }
     }
+    BFIR_STAMP(2, 10);
+}
+
+// ---------------------------------------------------------------------------
+// k_mac_stream: the time-streaming form of the same sums (fp32, B <= PB)
+// ---------------------------------------------------------------------------
+// One lane owns ONE bin of one channel for a range of output blocks and keeps
+// all PB filter partitions of that bin (2 PB registers) plus PB rotating
+// accumulators (2 PB registers) resident.  It walks the delay line backwards in
+// time: each spectrum value x[t] is loaded exactly once (two 4-byte loads per
+// lane, 16-byte runs across the wave) and feeds the PB outputs it contributes to,
+//     y[t + p] += x[t] * h[p],   p = 0 .. PB-1,
+// so output y[t'] receives p = 0 first and p = PB-1 last -- the reference's
+// partition order with the same fma chain as k_mac, hence bit-identical sums --
+// and is stored the moment its last partition has been added.  128 FMAs per
+// 8 bytes loaded, no LDS, no barrier, loads D blocks ahead in a register queue.
+// A range of R = ngrp*PB blocks costs exactly R*PB complex MACs: the newest
+// group only feeds outputs inside the range (MODE 0, a triangle), the PB-1
+// blocks before the range only feed its oldest outputs (MODE 2, the
+// complementary triangle), the groups in between are full (MODE 1).
+// Partitions p >= nblk[gc] hold h = 0 (an exact no-op on the sums).
+// Bin 0 (DC | Nyquist, two independent real sums) is left to the first blocks
+// of the grid (one thread per channel and output block); the streaming lanes
+// never store it.
+// compile-time loop: f(integral_constant<int, I>) for I = LO .. HI-1 (register arrays keep constant indices)
+template <int LO, int HI, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
+template <int PB, int D, int MODE>
+__device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB], const float (&hr)[PB],
+                                                 const float (&hi)[PB], float (&qr)[D], float (&qi)[D],
+                                                 const float *__restrict__ Xc, float *__restrict__ Yc, unsigned off,
+                                                 int N, int ring, int &sq, int tg, int n_t, bool store_lane)
+{
+    static_assert(PB % D == 0, "queue depth must divide the group");
+    constexpr int NU = MODE == 2 ? PB - 1 : PB;          // the block PB before the range feeds nothing
+    static_for<0, NU>([&](auto U) {                      // spectrum of block t = tg + PB-1-u
+        constexpr int u = decltype(U)::value;
+        const float xr = qr[u % D], xi = qi[u % D];
+        {   // uniform base + 32-bit lane offset: scalar address arithmetic only
+            const float *__restrict__ xb = Xc + (long)sq * N;
+            qr[u % D] = xb[off]; qi[u % D] = xb[off + 4];
+        }
+        sq -= 1; if (sq < 0) sq += ring;
+        const float nxi = -xi;
+        constexpr int plo = MODE == 2 ? u + 1 : 0, phi = MODE == 0 ? u : PB - 1;
+        static_for<plo, phi + 1>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            constexpr int sl = (PB - 1 - u + p) % PB;    // accumulator of y[t + p]
+            if constexpr (p == 0) {
+                ar[sl] = fmaf(xr, hr[0], 0.f); ar[sl] = fmaf(nxi, hi[0], ar[sl]);
+                ai[sl] = fmaf(xr, hi[0], 0.f); ai[sl] = fmaf(xi, hr[0], ai[sl]);
+            } else {
+                ar[sl] = fmaf(xr, hr[p], ar[sl]); ar[sl] = fmaf(nxi, hi[p], ar[sl]);
+                ai[sl] = fmaf(xr, hi[p], ai[sl]); ai[sl] = fmaf(xi, hr[p], ai[sl]);
+            }
+            // pin the sums here: otherwise the compiler sinks every chain down to its (conditional)
+            // store, which keeps a whole group of spectra live and serialises each chain
+            asm volatile("" : "+v"(ar[sl]), "+v"(ai[sl]));
+        });
+        if constexpr (phi == PB - 1) {                   // y[t + PB-1] is complete
+            constexpr int sl = (2 * PB - 2 - u) % PB;
+            const int ty = tg + 2 * PB - 2 - u;
+            if (ty < n_t && store_lane) {
+                float *yo = Yc + (long)ty * N;
+                yo[off] = ar[sl]; yo[off + 4] = ai[sl];
+            }
+        }
+    });
+}
+
+template <int PB, int D>
+__global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int nR, int ngrp, int n_dc)
+{
+    const int N = a.N, ring = a.ring;
+    if ((int)blockIdx.x < n_dc) {
+        // DC / Nyquist: slots 0 and 4 of group 0, two independent real sums in partition order.
+        // One workgroup = one channel x 256 output blocks: the 256+PB-1 delay-line values and the
+        // PB filter values go through LDS in one round of (scattered, but concurrent) loads, then
+        // every thread runs its own chain out of LDS.
+        __shared__ float s_x[2][256 + PB], s_hh[2][PB];
+        const int ndt = (a.n_t + 255) / 256;
+        const int gc = blockIdx.x / ndt, t0 = (blockIdx.x - gc * ndt) * 256;
+        const float *__restrict__ X = (const float *)a.x + (long)gc * a.x_ch_stride;
+        const float *__restrict__ H = (const float *)a.h + (long)gc * a.h_ch_stride;
+        const int nb = a.nblk[gc];
+        for (int i = threadIdx.x; i < 256 + PB - 1; i += 256) {      // s_x[.][i] = block t0 - (PB-1) + i
+            int sl = (a.base_slot + t0 - (PB - 1) + i) % ring; if (sl < 0) sl += ring;
+            s_x[0][i] = X[(long)sl * N]; s_x[1][i] = X[(long)sl * N + 4];
+        }
+        if (threadIdx.x < PB) {
+            const int p = threadIdx.x;
+            s_hh[0][p] = p < nb ? H[(long)p * N] : 0.f; s_hh[1][p] = p < nb ? H[(long)p * N + 4] : 0.f;
+        }
+        __syncthreads();
+        const int t = t0 + threadIdx.x;
+        if (t >= a.n_t) return;
+        float dc = 0.f, ny = 0.f;
+        for (int p = 0; p < nb; p++) {
+            dc = fmaf(s_x[0][threadIdx.x + PB - 1 - p], s_hh[0][p], dc);
+            ny = fmaf(s_x[1][threadIdx.x + PB - 1 - p], s_hh[1][p], ny);
+        }
+        float *yo = (float *)a.y + (long)gc * a.y_ch_stride + (long)t * N;
+        yo[0] = dc; yo[4] = ny;
+        return;
+    }
+    // XCD-aware bijective remap (see k_mac): (channel, bin column) major, time range minor
+    const int W = gridDim.x - n_dc, b = blockIdx.x - n_dc, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nR, r = w - s * nR;
+    const int gc = s / ncol, col = s - gc * ncol;
+    const int k = col * 256 + threadIdx.x;               // bin; a wave covers 16 whole groups
+    const unsigned off = 8u * (k >> 2) + (k & 3);
+    const float *__restrict__ Xc = (const float *)a.x + (long)gc * a.x_ch_stride;
+    const float *__restrict__ Hc = (const float *)a.h + (long)gc * a.h_ch_stride;
+    float *__restrict__ Yc = (float *)a.y + (long)gc * a.y_ch_stride;
+    const int nb = a.nblk[gc];
+    const int R = ngrp * PB, ta = r * R;
+    BFIR_STAMP(2, 0);
+
+    float qr[D], qi[D];
+    int sq = (a.base_slot + ta + R - 1) % ring;          // newest block of the range first
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const float *__restrict__ xb = Xc + (long)sq * N;
+        qr[d] = xb[off]; qi[d] = xb[off + 4];
+        sq -= 1; if (sq < 0) sq += ring;
+    }
+    float hr[PB], hi[PB];
+#pragma unroll
+    for (int p = 0; p < PB; p++) {
+        if (p < nb) { const float *__restrict__ hb = Hc + (long)p * N; hr[p] = hb[off]; hi[p] = hb[off + 4]; }
+        else { hr[p] = 0.f; hi[p] = 0.f; }
+    }
+    float ar[PB], ai[PB];
+#pragma unroll
+    for (int p = 0; p < PB; p++) { ar[p] = 0.f; ai[p] = 0.f; }
+    const bool store_lane = k != 0;
+    int tg = ta + R - PB;
+    BFIR_STAMP(2, 1);
+    mac_stream_group<PB, D, 0>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+    BFIR_STAMP(2, 2);
+    for (int g = ngrp - 2; g >= 0; g--) {
+        tg -= PB;
+        mac_stream_group<PB, D, 1>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+    }
+    BFIR_STAMP(2, 3);
+    tg -= PB;
+    mac_stream_group<PB, D, 2>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+    BFIR_STAMP(2, 4);
+}
+
+// ngrp: groups of PB blocks per wave (BFIR_MAC_RANGE overrides, in blocks)
+template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStream_t s)
+{
+    static int range_env = -1;
+    if (range_env < 0) { const char *e = getenv("BFIR_MAC_RANGE"); range_env = e ? atoi(e) : 0; }
+    const int ncol = a.N / 2 / 256;                      // workgroup columns of 256 bins
+    int ngrp;
+    if (range_env > 0) ngrp = std::max(1, range_env / PB);
+    else {
+        // enough waves for ~3 per SIMD (1024 SIMDs), but no shorter than one group
+        const long cols = (long)ncol * a.n_ch;
+        const long want = std::max<long>(1, 768 / cols);
+        ngrp = std::max(1, (int)((a.n_t + want * PB - 1) / (want * PB)));
+    }
+    const int R = ngrp * PB, nR = (a.n_t + R - 1) / R;
+    const int n_dc = a.n_ch * ((a.n_t + 255) / 256);
+    hipLaunchKernelGGL((k_mac_stream<PB, D>), dim3(n_dc + nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, ngrp, n_dc);
 }
 
 template <int D> static void launch_mac_lds(const MacArgs &a, hipStream_t s)
@@ -604,8 +790,18 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     const int tt = a.n_t;
     if (a.realsize == 4) {
         const int v = mac_variant();
+        // time-streaming kernel: every partition of a bin in registers (B <= 32), whole 256-bin columns,
+        // and at least one group of blocks so the triangles are not mostly waste
+        const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
+        const bool stream_ok = a.N >= 512 && a.B >= 1 && a.B <= 32 && tt >= pb;
         const bool lds_ok = a.N >= 512 && tt >= 32;   // 64-group tiles, 32-block time tiles
-        if (lds_ok && v == 0) launch_mac_lds<8>(a, s);
+        if (stream_ok && v == 0) {
+            if (pb == 4) launch_mac_stream<4, 4>(a, s);
+            else if (pb == 8) launch_mac_stream<8, 8>(a, s);
+            else if (pb == 16) launch_mac_stream<16, 8>(a, s);
+            else launch_mac_stream<32, 8>(a, s);
+        }
+        else if (lds_ok && (v == 0 || v == 8)) launch_mac_lds<8>(a, s);
         else if (lds_ok && v == 6) launch_mac_lds<4>(a, s);
         else if (lds_ok && v == 7) launch_mac_lds<2>(a, s);
         else if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);
@@ -1115,3 +1311,14 @@ void launch_cmul_stage(const void *b, const void *c, void *d, int n_fft, int mod
 }
 
 }  // namespace bfir
+
+#ifdef BFIR_TRACE
+// tuning builds only: copy the phase stamps of kernel `kern` (0 k_fwd, 1 k_inv, 2 k_mac_lds)
+extern "C" int bfir_debug_read_trace(int kern, unsigned long long *out, int n_wgs)
+{
+    if (kern < 0 || kern > 2 || n_wgs > BFIR_TRACE_WGS) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n_wgs * BFIR_TRACE_SLOTS,
+                                    sizeof(unsigned long long) * kern * BFIR_TRACE_WGS * BFIR_TRACE_SLOTS,
+                                    hipMemcpyDeviceToHost);
+}
+#endif

@@ -117,6 +117,9 @@ struct bfir_engine {
     hipEvent_t ev_entry = nullptr, ev_fwd[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr};
     hipEvent_t ev_inv[2] = {nullptr, nullptr};
     bool pipe3 = true;                     // BFIR_PIPE=2: MAC on the caller's stream (two-stage schedule)
+    // spectra (X, H, Y) as (re, im) pairs instead of the reference's 4 re | 4 im groups: the layout
+    // of the fp32 streaming MAC kernel; chosen once per engine (N >= 512, B <= 32, fp32)
+    bool ilv = false;
     bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
@@ -241,6 +244,10 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     e->in_scale = fmt_info(in_format).isfloat ? 1.0 : 1.0 / fmt_full_scale(in_format);
     e->out_scale = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format);
     e->of_max = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format) - 1.0;
+    {   // BFIR_MAC_VARIANT != 0 (tuning aid) keeps the grouped layout and the other MAC kernels
+        const char *mv = getenv("BFIR_MAC_VARIANT");
+        e->ilv = realsize == 4 && e->N >= 512 && e->B <= 32 && !(mv && atoi(mv) != 0);
+    }
     if (const char *pm = getenv("BFIR_PIPE")) { e->pipe3 = atoi(pm) >= 3; e->serial = atoi(pm) == 1; }
     e->nblk.assign(e->GC, 0);
     e->eng_init.assign(n_engines, 0);
@@ -370,6 +377,7 @@ extern "C" int bfir_engine_set_coeff_at(bfir_engine *e, int engine_index, const 
     fa.load_scale = scale;
     fa.out_scale = 1.0 / (double)e->N;                          // fftw_convolver.cpp:520
     fa.zero_first_half = 1;
+    fa.interleaved = e->ilv;
     launch_fwd(e->plan, fa, e->stream);
     for (int n = 0; n < e->C; n++) e->nblk[gc0 + n] = nb;
     HIP_TRY(hipMemcpyAsync(e->d_nblk + gc0, e->nblk.data() + gc0, sizeof(int) * e->C,
@@ -394,6 +402,14 @@ extern "C" int bfir_engine_read_coeff(bfir_engine *e, int channel, int block, vo
     HIP_TRY(hipDeviceSynchronize());
     const size_t cb = cbuf_bytes(e);
     HIP_TRY(hipMemcpy(dst, (char *)e->H + ((size_t)channel * e->B + block) * cb, cb, hipMemcpyDeviceToHost));
+    if (e->ilv) {   // hand out the reference's grouped layout (fftw_convolver.cpp:883-907); ilv engines are fp32
+        std::vector<float> tmp((const float *)dst, (const float *)dst + e->N);
+        float *o = (float *)dst;
+        for (int k = 0; k < e->N / 2; k++) {
+            o[8 * (k >> 2) + (k & 3)] = tmp[2 * k];
+            o[8 * (k >> 2) + 4 + (k & 3)] = tmp[2 * k + 1];
+        }
+    }
     return BFIR_OK;
 }
 
@@ -507,6 +523,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.n_t = tc; a.n_ch = e->GC;
         a.load_scale = 1.0; a.out_scale = e->in_scale;
         a.zero_first_half = 0;
+        a.interleaved = e->ilv;
         launch_fwd(e->plan, a, sf);
     }
     HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
@@ -522,6 +539,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.nblk = e->d_nblk;
         a.y = Y; a.y_ch_stride = (long)e->chunk * e->N;
         a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s; a.B = e->B;
+        a.interleaved = e->ilv;
         launch_mac(a, sm);
     }
     HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
@@ -534,6 +552,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.n_t = tc; a.n_ch = e->GC;
         a.in_scale = e->out_scale;
         a.full_output = 0;
+        a.interleaved = e->ilv;
         launch_inv(e->plan, a, st);
     }
     if (e->pipe3) HIP_TRY(hipEventRecord(e->ev_inv[par], st));

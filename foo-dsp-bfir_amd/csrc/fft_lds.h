@@ -47,6 +47,17 @@ static __device__ unsigned long long g_trace[3][BFIR_TRACE_WGS * BFIR_TRACE_SLOT
 
 namespace bfir {
 
+// Force the values to exist in registers at this point of the program.  LLVM's sinking passes
+// otherwise move an LDS read (and the arithmetic hanging off it) down to its first use even when
+// that use sits behind a __syncthreads() in a conditional block -- observed on k_fwd<float,14>:
+// ten of the sixteen Z[M-k] reads of the split step landed after the barrier that protects them,
+// racing with the staging writes of other waves.  Costs no instruction.
+template <typename T, int P> __device__ __forceinline__ void pin_registers(T (&re)[P], T (&im)[P])
+{
+#pragma unroll
+    for (int e = 0; e < P; e++) asm volatile("" : "+v"(re[e]), "+v"(im[e]));
+}
+
 template <typename T> struct Vec2;
 template <> struct Vec2<float>  { using type = float2; };
 template <> struct Vec2<double> { using type = double2; };
@@ -291,6 +302,9 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
                 V2 v = lds[phys((tid + b * NT) + r * (M / Rn))];
                 re[b * Rn + r] = v.x; im[b * Rn + r] = v.y;
             }
+        // the reads must not sink below the next barrier (see pin_registers)
+#pragma unroll
+        for (int e = 0; e < P; e++) asm volatile("" : "+v"(re[e]), "+v"(im[e]));
     }
 
     // Full transform of the P register points (in_index order in, out_index order out).

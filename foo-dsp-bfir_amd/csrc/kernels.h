@@ -85,6 +85,7 @@ struct FwdArgs {
     int n_t, n_ch;
     double load_scale, out_scale;
     int zero_first_half;
+    int interleaved = 0;           // spectrum layout: 0 = the reference's groups (4 re | 4 im), 1 = (re, im) pairs
 };
 void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s);
 
@@ -96,6 +97,7 @@ struct MacArgs {
     void *y; long y_ch_stride;                     // [gc][n_t][N]
     int n_t, n_ch, N, realsize;
     int B = 0;                                     // partitions allocated per channel (max of nblk)
+    int interleaved = 0;                           // layout of x, h and y, as in FwdArgs (fp32 streaming kernel only)
 };
 void launch_mac(const MacArgs &a, hipStream_t s);
 
@@ -107,6 +109,7 @@ struct InvArgs {
     int n_t, n_ch;
     double in_scale;
     int full_output;                               // 1: write all N samples at stride N (stage API)
+    int interleaved = 0;                           // layout of src, as in FwdArgs
 };
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
 

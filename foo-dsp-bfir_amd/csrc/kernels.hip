@@ -110,7 +110,7 @@ void fft_plan_destroy(FftPlan *plan)
 // ---------------------------------------------------------------------------
 // a6 + a7: forward real FFT into the grouped layout
 // ---------------------------------------------------------------------------
-template <typename T, int LOG2M>
+template <typename T, int LOG2M, bool ILV>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
                                                            const typename Vec2<T>::type *__restrict__ tw,
                                                            const typename Vec2<T>::type *__restrict__ ws)
@@ -173,14 +173,20 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
         if (k == 0) xi = re[e] - im[e];  // slot 4 carries Re X_{N/2}
         re[e] = xr * os; im[e] = xi * os;
     }
+    pin_registers(re, im);   // every Z[M-k] read happens before the barrier
     BFIR_STAMP(0, 9);
     __syncthreads();
     T *ldsr = (T *)lds;
 #pragma unroll
     for (int e = 0; e < P; e++) {
         const int k = F::out_index(tid, e);
-        ldsr[8 * (k >> 2) + (k & 3)] = re[e];
-        ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
+        if constexpr (ILV) {               // (re, im) pairs: slot 2k | 2k+1 (bin 0: DC | Nyquist)
+            V2 v; v.x = re[e]; v.y = im[e];
+            ((V2 *)ldsr)[k] = v;
+        } else {                           // the reference's groups: 4 re then 4 im
+            ldsr[8 * (k >> 2) + (k & 3)] = re[e];
+            ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -196,8 +202,17 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
     using V2 = typename Vec2<T>::type;
     // a transform whose LDS buffer would not fit one CU is never instantiated
     if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
-        hipLaunchKernelGGL((k_fwd<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+    {
+        if constexpr (sizeof(T) == 4) {
+            if (a.interleaved) {
+                hipLaunchKernelGGL((k_fwd<T, LOG2M, true>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                   (const V2 *)plan.tw, (const V2 *)plan.ws);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_fwd<T, LOG2M, false>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
                            (const V2 *)plan.tw, (const V2 *)plan.ws);
+    }
 }
 
 void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
@@ -218,7 +233,7 @@ void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // a11 + a12: inverse real FFT from the grouped layout, valid half only
 // ---------------------------------------------------------------------------
-template <typename T, int LOG2M>
+template <typename T, int LOG2M, bool ILV>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
                                                            const typename Vec2<T>::type *__restrict__ tw,
                                                            const typename Vec2<T>::type *__restrict__ ws)
@@ -252,14 +267,21 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
     for (int e = 0; e < P; e++) {
         const int k = F::in_index(tid, e);
         const int q = (k == 0) ? 0 : M - k;
-        T xr = ldsr[8 * (k >> 2) + (k & 3)] * sc, xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
-        T yr = ldsr[8 * (q >> 2) + (q & 3)] * sc, yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+        T xr, xi, yr, yi;
+        if constexpr (ILV) {
+            const V2 vx = ((const V2 *)ldsr)[k], vy = ((const V2 *)ldsr)[q];
+            xr = vx.x * sc; xi = vx.y * sc; yr = vy.x * sc; yi = vy.y * sc;
+        } else {
+            xr = ldsr[8 * (k >> 2) + (k & 3)] * sc; xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
+            yr = ldsr[8 * (q >> 2) + (q & 3)] * sc; yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+        }
         if (k == 0) { yr = xi; xi = (T)0; yi = (T)0; }  // X_0 = (DC, 0), X_M = (Nyquist, 0)
         V2 w = ws[k];
         T ar = xr + yr, ai = xi - yi, br = xr - yr, bi = xi + yi;
         T tr = br * w.x + bi * w.y, ti = bi * w.x - br * w.y;
         re[e] = ar - ti; im[e] = ai + tr;
     }
+    pin_registers(re, im);   // every read of the staged spectrum happens before run()'s first barrier
 
     BFIR_STAMP(1, 1);
     F::run(re, im, lds, tw, tid);
@@ -280,8 +302,17 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
     using V2 = typename Vec2<T>::type;
     // a transform whose LDS buffer would not fit one CU is never instantiated
     if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
-        hipLaunchKernelGGL((k_inv<T, LOG2M>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+    {
+        if constexpr (sizeof(T) == 4) {
+            if (a.interleaved) {
+                hipLaunchKernelGGL((k_inv<T, LOG2M, true>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                   (const V2 *)plan.tw, (const V2 *)plan.ws);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_inv<T, LOG2M, false>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
                            (const V2 *)plan.tw, (const V2 *)plan.ws);
+    }
 }
 
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s)
@@ -587,8 +618,9 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
 // One lane owns ONE bin of one channel for a range of output blocks and keeps
 // all PB filter partitions of that bin (2 PB registers) plus PB rotating
 // accumulators (2 PB registers) resident.  It walks the delay line backwards in
-// time: each spectrum value x[t] is loaded exactly once (two 4-byte loads per
-// lane, 16-byte runs across the wave) and feeds the PB outputs it contributes to,
+// time: each spectrum value x[t] is loaded exactly once (one 8-byte load per lane,
+// 512 contiguous bytes per wave: the engine keeps X, H and Y as (re, im) pairs
+// for this kernel -- MacArgs.interleaved) and feeds the PB outputs it contributes to,
 //     y[t + p] += x[t] * h[p],   p = 0 .. PB-1,
 // so output y[t'] receives p = 0 first and p = PB-1 last -- the reference's
 // partition order with the same fma chain as k_mac, hence bit-identical sums --
@@ -613,19 +645,16 @@ template <int LO, int HI, typename F> __device__ __forceinline__ void static_for
 
 template <int PB, int D, int MODE>
 __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB], const float (&hr)[PB],
-                                                 const float (&hi)[PB], float (&qr)[D], float (&qi)[D],
-                                                 const float *__restrict__ Xc, float *__restrict__ Yc, unsigned off,
-                                                 int N, int ring, int &sq, int tg, int n_t, bool store_lane)
+                                                 const float (&hi)[PB], float2 (&q)[D],
+                                                 const float2 *__restrict__ Xc, float2 *__restrict__ Yc, unsigned k,
+                                                 int N2, int ring, int &sq, int tg, int n_t, bool store_lane)
 {
     static_assert(PB % D == 0, "queue depth must divide the group");
     constexpr int NU = MODE == 2 ? PB - 1 : PB;          // the block PB before the range feeds nothing
     static_for<0, NU>([&](auto U) {                      // spectrum of block t = tg + PB-1-u
         constexpr int u = decltype(U)::value;
-        const float xr = qr[u % D], xi = qi[u % D];
-        {   // uniform base + 32-bit lane offset: scalar address arithmetic only
-            const float *__restrict__ xb = Xc + (long)sq * N;
-            qr[u % D] = xb[off]; qi[u % D] = xb[off + 4];
-        }
+        const float xr = q[u % D].x, xi = q[u % D].y;
+        q[u % D] = (Xc + (long)sq * N2)[k];              // uniform base + 32-bit lane offset, 8 bytes per lane
         sq -= 1; if (sq < 0) sq += ring;
         const float nxi = -xi;
         constexpr int plo = MODE == 2 ? u + 1 : 0, phi = MODE == 0 ? u : PB - 1;
@@ -647,8 +676,8 @@ __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB
             constexpr int sl = (2 * PB - 2 - u) % PB;
             const int ty = tg + 2 * PB - 2 - u;
             if (ty < n_t && store_lane) {
-                float *yo = Yc + (long)ty * N;
-                yo[off] = ar[sl]; yo[off + 4] = ai[sl];
+                float2 v; v.x = ar[sl]; v.y = ai[sl];
+                (Yc + (long)ty * N2)[k] = v;
             }
         }
     });
@@ -671,11 +700,11 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
         const int nb = a.nblk[gc];
         for (int i = threadIdx.x; i < 256 + PB - 1; i += 256) {      // s_x[.][i] = block t0 - (PB-1) + i
             int sl = (a.base_slot + t0 - (PB - 1) + i) % ring; if (sl < 0) sl += ring;
-            s_x[0][i] = X[(long)sl * N]; s_x[1][i] = X[(long)sl * N + 4];
+            s_x[0][i] = X[(long)sl * N]; s_x[1][i] = X[(long)sl * N + 1];
         }
         if (threadIdx.x < PB) {
             const int p = threadIdx.x;
-            s_hh[0][p] = p < nb ? H[(long)p * N] : 0.f; s_hh[1][p] = p < nb ? H[(long)p * N + 4] : 0.f;
+            s_hh[0][p] = p < nb ? H[(long)p * N] : 0.f; s_hh[1][p] = p < nb ? H[(long)p * N + 1] : 0.f;
         }
         __syncthreads();
         const int t = t0 + threadIdx.x;
@@ -686,7 +715,7 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
             ny = fmaf(s_x[1][threadIdx.x + PB - 1 - p], s_hh[1][p], ny);
         }
         float *yo = (float *)a.y + (long)gc * a.y_ch_stride + (long)t * N;
-        yo[0] = dc; yo[4] = ny;
+        yo[0] = dc; yo[1] = ny;
         return;
     }
     // XCD-aware bijective remap (see k_mac): (channel, bin column) major, time range minor
@@ -694,27 +723,26 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
     const int s = w / nR, r = w - s * nR;
     const int gc = s / ncol, col = s - gc * ncol;
-    const int k = col * 256 + threadIdx.x;               // bin; a wave covers 16 whole groups
-    const unsigned off = 8u * (k >> 2) + (k & 3);
-    const float *__restrict__ Xc = (const float *)a.x + (long)gc * a.x_ch_stride;
-    const float *__restrict__ Hc = (const float *)a.h + (long)gc * a.h_ch_stride;
-    float *__restrict__ Yc = (float *)a.y + (long)gc * a.y_ch_stride;
+    const unsigned k = col * 256 + threadIdx.x;          // bin: (re, im) pair k of every spectrum
+    const int N2 = N / 2;
+    const float2 *__restrict__ Xc = (const float2 *)((const float *)a.x + (long)gc * a.x_ch_stride);
+    const float2 *__restrict__ Hc = (const float2 *)((const float *)a.h + (long)gc * a.h_ch_stride);
+    float2 *__restrict__ Yc = (float2 *)((float *)a.y + (long)gc * a.y_ch_stride);
     const int nb = a.nblk[gc];
     const int R = ngrp * PB, ta = r * R;
     BFIR_STAMP(2, 0);
 
-    float qr[D], qi[D];
+    float2 q[D];
     int sq = (a.base_slot + ta + R - 1) % ring;          // newest block of the range first
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const float *__restrict__ xb = Xc + (long)sq * N;
-        qr[d] = xb[off]; qi[d] = xb[off + 4];
+        q[d] = (Xc + (long)sq * N2)[k];
         sq -= 1; if (sq < 0) sq += ring;
     }
     float hr[PB], hi[PB];
 #pragma unroll
     for (int p = 0; p < PB; p++) {
-        if (p < nb) { const float *__restrict__ hb = Hc + (long)p * N; hr[p] = hb[off]; hi[p] = hb[off + 4]; }
+        if (p < nb) { const float2 h = (Hc + (long)p * N2)[k]; hr[p] = h.x; hi[p] = h.y; }
         else { hr[p] = 0.f; hi[p] = 0.f; }
     }
     float ar[PB], ai[PB];
@@ -723,15 +751,15 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     const bool store_lane = k != 0;
     int tg = ta + R - PB;
     BFIR_STAMP(2, 1);
-    mac_stream_group<PB, D, 0>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 0>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
     BFIR_STAMP(2, 2);
     for (int g = ngrp - 2; g >= 0; g--) {
         tg -= PB;
-        mac_stream_group<PB, D, 1>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+        mac_stream_group<PB, D, 1>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
     }
     BFIR_STAMP(2, 3);
     tg -= PB;
-    mac_stream_group<PB, D, 2>(ar, ai, hr, hi, qr, qi, Xc, Yc, off, N, ring, sq, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 2>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
     BFIR_STAMP(2, 4);
 }
 
@@ -790,18 +818,17 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     const int tt = a.n_t;
     if (a.realsize == 4) {
         const int v = mac_variant();
-        // time-streaming kernel: every partition of a bin in registers (B <= 32), whole 256-bin columns,
-        // and at least one group of blocks so the triangles are not mostly waste
+        // time-streaming kernel: every partition of a bin in registers (B <= 32), whole 256-bin columns
         const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
-        const bool stream_ok = a.N >= 512 && a.B >= 1 && a.B <= 32 && tt >= pb;
-        const bool lds_ok = a.N >= 512 && tt >= 32;   // 64-group tiles, 32-block time tiles
-        if (stream_ok && v == 0) {
+        if (a.interleaved) {                          // the engine picked the pair layout: N >= 512, B <= 32
             if (pb == 4) launch_mac_stream<4, 4>(a, s);
             else if (pb == 8) launch_mac_stream<8, 8>(a, s);
             else if (pb == 16) launch_mac_stream<16, 8>(a, s);
             else launch_mac_stream<32, 8>(a, s);
+            return;
         }
-        else if (lds_ok && (v == 0 || v == 8)) launch_mac_lds<8>(a, s);
+        const bool lds_ok = a.N >= 512 && tt >= 32;   // 64-group tiles, 32-block time tiles
+        if (lds_ok && (v == 0 || v == 8)) launch_mac_lds<8>(a, s);
         else if (lds_ok && v == 6) launch_mac_lds<4>(a, s);
         else if (lds_ok && v == 7) launch_mac_lds<2>(a, s);
         else if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);

@@ -91,7 +91,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    # BFIR_LIB_OVERRIDE: load another build of the library (A/B timing of two builds in one gpurun call)
+    return os.environ.get("BFIR_LIB_OVERRIDE") or _build.LIB
 
 
 def _share_hip_runtime_with_torch():

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <vector>
 
 #include "../../include/bfir_hip.h"
@@ -120,6 +121,14 @@ struct bfir_engine {
     // spectra (X, H, Y) as (re, im) pairs instead of the reference's 4 re | 4 im groups: the layout
     // of the fp32 streaming MAC kernel; chosen once per engine (N >= 512, B <= 32, fp32)
     bool ilv = false;
+    // pair path (pair.hip): FLOAT_LE in and out, even channel count, 512 <= L <= 8192 on top of ilv.
+    // No planar time buffers; the engine's time history is the raw frames of the last two blocks,
+    // tails[set][i] = [n_eng][L][C] floats, set alternating per chunk so a launch never reads and
+    // writes the same copy; hist_raw[i] is where input_timecbuf[n][i]'s first half currently lives.
+    bool pair = false;
+    FftPlan plan2;                         // transform of 2L complex points
+    float *tails[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    const float *hist_raw[2] = {nullptr, nullptr};
     bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
@@ -183,9 +192,11 @@ static int alloc_work(bfir_engine *e, int chunk)
     HIP_TRY(hipMalloc(&X, (size_t)e->GC * ring * cb));
     HIP_TRY(hipMalloc(&Y0, (size_t)e->GC * chunk * cb));
     HIP_TRY(hipMalloc(&Y1, (size_t)e->GC * chunk * cb));
-    HIP_TRY(hipMalloc(&tin0, (size_t)e->GC * chunk * e->L * e->s));
-    HIP_TRY(hipMalloc(&tin1, (size_t)e->GC * chunk * e->L * e->s));
-    HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
+    if (!e->pair) {   // the pair path has no planar time buffers
+        HIP_TRY(hipMalloc(&tin0, (size_t)e->GC * chunk * e->L * e->s));
+        HIP_TRY(hipMalloc(&tin1, (size_t)e->GC * chunk * e->L * e->s));
+        HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
+    }
     HIP_TRY(hipMemset(X, 0, (size_t)e->GC * ring * cb));
     if (e->X) {
         // keep the last B-1 spectra: absolute block j lives in slot j % ring
@@ -248,12 +259,28 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         const char *mv = getenv("BFIR_MAC_VARIANT");
         e->ilv = realsize == 4 && e->N >= 512 && e->B <= 32 && !(mv && atoi(mv) != 0);
     }
+    {   // BFIR_PAIR=0 (tuning aid) keeps the planar staging kernels
+        const char *pv = getenv("BFIR_PAIR");
+        e->pair = e->ilv && in_format == 8 && out_format == 8 && (channels % 2) == 0 &&
+                  pair_supported(filter_length) && !(pv && atoi(pv) == 0);
+    }
     if (const char *pm = getenv("BFIR_PIPE")) { e->pipe3 = atoi(pm) >= 3; e->serial = atoi(pm) == 1; }
     e->nblk.assign(e->GC, 0);
     e->eng_init.assign(n_engines, 0);
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
     if (rc != 0) { *err = (rc == -1) ? BFIR_ERR_UNSUPPORTED : BFIR_ERR_HIP; delete e; return nullptr; }
     auto fail = [&](int code) { *err = code; bfir_engine_destroy(e); return (bfir_engine *)nullptr; };
+    if (e->pair) {
+        if (fft_plan_create(&e->plan2, 2 * filter_length, 4) != 0) return fail(BFIR_ERR_HIP);
+        const size_t tb = (size_t)e->n_eng * e->L * e->C * sizeof(float);
+        for (int st = 0; st < 2; st++)
+            for (int i = 0; i < 2; i++) {
+                if (hipMalloc((void **)&e->tails[st][i], tb) != hipSuccess) return fail(BFIR_ERR_HIP);
+                (void)hipMemset(e->tails[st][i], 0, tb);   // input_timecbuf starts zeroed (brutefir.cpp:769)
+            }
+        // chunk 0 writes set 0, so the (zero) history it reads lives in set 1
+        e->hist_raw[0] = e->tails[1][0]; e->hist_raw[1] = e->tails[1][1];
+    }
     hipStream_t *streams[] = {&e->stream, &e->s_front, &e->s_mac, &e->s_in, &e->s_out};
     for (hipStream_t *st : streams)
         if (hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return fail(BFIR_ERR_HIP);
@@ -300,6 +327,8 @@ extern "C" void bfir_engine_destroy(bfir_engine *e)
     (void)hipDeviceSynchronize();
     free_work(e);
     fft_plan_destroy(&e->plan);
+    fft_plan_destroy(&e->plan2);
+    for (int st = 0; st < 2; st++) for (int i = 0; i < 2; i++) if (e->tails[st][i]) (void)hipFree(e->tails[st][i]);
     void *bufs[] = {e->H, e->saved[0], e->saved[1], e->d_nblk, e->d_of, e->d_bad};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto &sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -489,9 +518,77 @@ extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total
 // events / stream order.  So fwd(k+1), mac(k) and inv/stage_out(k-1) share the
 // GPU: none of the kernels saturates VALU or HBM alone (load-latency phases,
 // profiles/r01_phase_trace.txt), together they fill each other's gaps.
+// The same chunk on the pair path: no staging kernels, no planar time buffers.
+//   s_front : fwd_pair(k)             raw frames -> delay-line spectra of two channels per transform
+//   s_mac   : mac(k)
+//   st      : inv_pair(k)             product spectra -> raw frames + overflow statistics
+static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
+                          long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
+{
+    if (((uintptr_t)d_in | (uintptr_t)d_out | (uintptr_t)in_stride | (uintptr_t)out_stride) & 7) {
+        bfir_logf("bfir engine: frame buffers of the float fast path must be 8-byte aligned.");
+        return BFIR_ERR_ARG;
+    }
+    const int par = (int)(e->chunk_seq & 1);
+    const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
+    hipStream_t sf = e->serial ? st : e->s_front;
+    hipStream_t sm = e->pipe3 ? e->s_mac : st;
+    if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
+    if (e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
+    // input_timecbuf bookkeeping as in run_chunk: block j of the chunk lands in buffer !(curbuf ^ (j & 1))
+    const int idx_last = 1 ^ e->curbuf ^ ((tc - 1) & 1);
+    {
+        ProfScope ps(e, BFIR_K_FWD, sf);
+        FwdPairArgs a;
+        a.raw = (const float *)d_in; a.eng_stride = in_stride / 4; a.frame_off = frame_off;
+        a.C = e->C; a.n_eng = e->n_eng; a.n_t = tc;
+        a.prev = e->hist_raw[e->curbuf];
+        a.save_last = e->tails[par][idx_last]; a.save_prev = e->tails[par][1 ^ idx_last];
+        a.carry = e->hist_raw[1 ^ idx_last];
+        a.hist_eng_stride = (long)e->L * e->C;
+        a.dst = (float *)e->X; a.dst_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
+        a.scale = (float)e->in_scale;
+        launch_fwd_pair(e->plan2, a, sf);
+    }
+    e->hist_raw[0] = e->tails[par][0]; e->hist_raw[1] = e->tails[par][1];
+    HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
+    HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
+    if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    void *Y = e->Yb[e->pipe3 ? par : 0];
+    {
+        ProfScope ps(e, BFIR_K_MAC, sm);
+        MacArgs a;
+        a.x = e->X; a.x_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
+        a.h = e->H; a.h_ch_stride = (long)e->B * e->N;
+        a.nblk = e->d_nblk;
+        a.y = Y; a.y_ch_stride = (long)e->chunk * e->N;
+        a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s; a.B = e->B;
+        a.interleaved = 1;
+        launch_mac(a, sm);
+    }
+    HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
+    if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    {
+        ProfScope ps(e, BFIR_K_INV, st);
+        InvPairArgs a;
+        a.y = (const float *)Y; a.y_ch_stride = (long)e->chunk * e->N;
+        a.raw = (float *)d_out; a.eng_stride = out_stride / 4; a.frame_off = frame_off;
+        a.C = e->C; a.n_eng = e->n_eng; a.n_t = tc;
+        a.scale = (float)e->out_scale; a.max = (float)e->of_max;
+        a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        launch_inv_pair(e->plan2, a, st);
+    }
+    if (e->pipe3) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
+    e->curbuf ^= (tc & 1);
+    e->blockcounter += (unsigned long long)tc;
+    e->chunk_seq += 1;
+    return BFIR_OK;
+}
+
 static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
                      long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
 {
+    if (e->pair) return run_chunk_pair(e, d_in, in_stride, d_out, out_stride, frame_off, tc, block_base, st, input_ready);
     const int par = (int)(e->chunk_seq & 1);
     const long t_stride = (long)e->chunk * e->L;
     void *tin = e->tin[par];

@@ -113,6 +113,29 @@ struct InvArgs {
 };
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
 
+// Pair path (pair.hip): two adjacent channels per complex transform, straight from / to interleaved
+// FLOAT_LE frames; fp32, even channel count, 512 <= L <= 8192.  `plan` is the plan of 2L points.
+bool pair_supported(int filter_length);
+struct FwdPairArgs {
+    const float *raw; long eng_stride; long frame_off;   // input frames; engine stride in floats
+    int C, n_eng, n_t;
+    const float *prev;                                   // the block before block 0: [n_eng][L][C] raw frames
+    float *save_last, *save_prev;                        // where blocks n_t-1 / n_t-2 are kept for the next chunk
+    const float *carry;                                  // n_t == 1: the history block that becomes save_prev
+    long hist_eng_stride;                                // floats between engines in prev / save_* / carry
+    float *dst; long dst_ch_stride; int ring, base_slot; // delay line, (re, im) pairs
+    float scale;
+};
+void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a, hipStream_t s);
+struct InvPairArgs {
+    const float *y; long y_ch_stride;                    // [gc][n_t][N] product spectra, (re, im) pairs
+    float *raw; long eng_stride; long frame_off;         // output frames
+    int C, n_eng, n_t;
+    float scale, max;
+    DevOverflow *overflow; int *bad_block; int block_base;
+};
+void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a, hipStream_t s);
+
 // mixnscale with one buffer (a7 / a11) on half-complex data, for the stage API.
 void launch_reorder(const void *in, void *out, int n_fft, double scale, int to_grouped, int realsize,
                     hipStream_t s);

@@ -729,7 +729,10 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     const float2 *__restrict__ Hc = (const float2 *)((const float *)a.h + (long)gc * a.h_ch_stride);
     float2 *__restrict__ Yc = (float2 *)((float *)a.y + (long)gc * a.y_ch_stride);
     const int nb = a.nblk[gc];
-    const int R = ngrp * PB, ta = r * R;
+    // this range: blocks ta .. ta+R-1; the last range of a launch only runs the groups it has blocks for
+    const int ta = r * ngrp * PB;
+    const int my_grp = min(ngrp, (a.n_t - ta + PB - 1) / PB);
+    const int R = my_grp * PB;
     BFIR_STAMP(2, 0);
 
     float2 q[D];
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     BFIR_STAMP(2, 1);
     mac_stream_group<PB, D, 0>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
     BFIR_STAMP(2, 2);
-    for (int g = ngrp - 2; g >= 0; g--) {
+    for (int g = my_grp - 2; g >= 0; g--) {
         tg -= PB;
         mac_stream_group<PB, D, 1>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
     }
@@ -772,9 +775,10 @@ template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStre
     int ngrp;
     if (range_env > 0) ngrp = std::max(1, range_env / PB);
     else {
-        // enough waves for ~3 per SIMD (1024 SIMDs), but no shorter than one group
+        // about 2048 waves (two per SIMD, one round: measured best, profiles/r01_mac_ranges.txt),
+        // never shorter than one group
         const long cols = (long)ncol * a.n_ch;
-        const long want = std::max<long>(1, 768 / cols);
+        const long want = std::max<long>(1, 512 / cols);
         ngrp = std::max(1, (int)((a.n_t + want * PB - 1) / (want * PB)));
     }
     const int R = ngrp * PB, nR = (a.n_t + R - 1) / R;

@@ -91,9 +91,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=4096,
+    ap.add_argument("--blocks", type=int, default=8192,
                     help="blocks per step (one run_device call; the chunk pipeline drains at call boundaries)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "512")),
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "2048")),
                     help="blocks per kernel launch")
     ap.add_argument("--workload", default="cfg3_8ch_131072tap_L4096_fp32", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0,

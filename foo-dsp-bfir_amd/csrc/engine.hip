@@ -96,7 +96,7 @@ struct bfir_engine {
     double in_scale = 1.0, out_scale = 1.0, of_max = 1.0;
     FftPlan plan;
     int chunk = 0, ring = 0;        // allocated geometry
-    int want_chunk = 128;
+    int want_chunk = 1024;                 // blocks per launch (bfir_engine_set_chunk); buffers are sized lazily
     void *H = nullptr, *X = nullptr, *Y = nullptr, *tout = nullptr;
     void *tin[2] = {nullptr, nullptr};
     void *Yb[2] = {nullptr, nullptr};      // product spectra, one buffer per chunk parity

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_fwd_pair(FwdPairArgs a, c
     const float *__restrict__ cur = a.raw + (long)g * a.eng_stride + (a.frame_off + (long)t * L) * C + 2 * cp;
     const float *__restrict__ old = (t == 0) ? a.prev + (long)g * a.hist_eng_stride + 2 * cp : cur - (long)L * C;
 
+    BFIR_STAMP(0, 0);
     float re[P], im[P];
 #pragma unroll
     for (int e = 0; e < P; e++) {
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_fwd_pair(FwdPairArgs a, c
         }
         re[e] = v.x * a.scale; im[e] = v.y * a.scale;
     }
+    BFIR_STAMP(0, 1);
 
     F::run(re, im, lds, tw, tid);
 
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_fwd_pair(FwdPairArgs a, c
         }
         da[k] = xa; db[k] = xb;
     }
+    BFIR_STAMP(0, 10);
 }
 
 template <int LOG2N>
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
     const int C = a.C;
     const int gc = g * C + 2 * cp;
 
+    BFIR_STAMP(1, 0);
     // both spectra into LDS: Ya at [0, L), Yb at [L, 2L)  (float2 units), 16 bytes per lane
     {
         const float4 *__restrict__ ya = (const float4 *)(a.y + (long)gc * a.y_ch_stride + (long)t * N);
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
         }
     }
     __syncthreads();
+    BFIR_STAMP(1, 9);
     // Z[k] = Ya[k] + i Yb[k], Hermitian-extended to the full circle
     float re[P], im[P];
 #pragma unroll
@@ -144,8 +149,10 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
         re[e] = zr * a.scale; im[e] = zi * a.scale;
     }
     pin_registers(re, im);   // every read of the staged spectra happens before run()'s first barrier
+    BFIR_STAMP(1, 1);
 
     F::run(re, im, lds, tw, tid);
+    BFIR_STAMP(1, 10);
 
     // first L samples are the valid half (the taps sit in the upper half of their blocks)
     float *__restrict__ out = a.raw + (long)g * a.eng_stride + (a.frame_off + (long)t * L) * C + 2 * cp;
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
         if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
             atomicMax(&of->largest_bits, (unsigned long long)m);
     }
+    BFIR_STAMP(1, 11);
 }
 
 }  // namespace
@@ -218,3 +226,14 @@ void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a, hipStream_t s)
 }
 
 }  // namespace bfir
+
+#ifdef BFIR_TRACE
+// tuning builds only: phase stamps of this file's kernels (0 k_fwd_pair, 1 k_inv_pair)
+extern "C" int bfir_debug_read_trace_pair(int kern, unsigned long long *out, int n_wgs)
+{
+    if (kern < 0 || kern > 1 || n_wgs > BFIR_TRACE_WGS) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n_wgs * BFIR_TRACE_SLOTS,
+                                    sizeof(unsigned long long) * kern * BFIR_TRACE_WGS * BFIR_TRACE_SLOTS,
+                                    hipMemcpyDeviceToHost);
+}
+#endif

@@ -11,6 +11,8 @@ chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 lib = _lib.load()
 lib.bfir_debug_read_trace.restype = ctypes.c_int
 lib.bfir_debug_read_trace.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+lib.bfir_debug_read_trace_pair.restype = ctypes.c_int
+lib.bfir_debug_read_trace_pair.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
 L, B, C = 4096, 32, 8
 eng = bf.Brutefir(L, B, 4, C)
 rng = np.random.default_rng(0)
@@ -24,20 +26,22 @@ for _ in range(3):
     eng.sync()
 torch.cuda.synchronize()
 
-names = {0: ("k_fwd", {0: "start", 1: "loaded", 2: "pass0", 3: "xchg0", 4: "pass1", 5: "xchg1", 6: "pass2", 9: "split", 10: "stored"}),
-         1: ("k_inv", {0: "start", 9: "lds-in", 1: "presplit", 2: "pass0", 3: "xchg0", 4: "pass1", 5: "xchg1", 6: "pass2", 10: "stored"}),
+names = {0: ("k_fwd_pair", {0: "start", 1: "loaded", 2: "pass0", 3: "xchg0", 4: "pass1", 5: "xchg1", 6: "pass2", 7: "xchg2", 8: "pass3", 10: "split+st"}),
+         1: ("k_inv_pair", {0: "start", 9: "lds-in", 1: "build-z", 2: "pass0", 3: "xchg0", 4: "pass1", 5: "xchg1", 6: "pass2", 7: "xchg2", 8: "pass3", 10: "run-end", 11: "stored"}),
          2: ("k_mac_stream", {0: "start", 1: "h+queue", 2: "head", 3: "full", 4: "tail"})}
 for kern, (nm, ph) in names.items():
-    nw = {0: chunk * C, 1: chunk * C, 2: 4096}[kern]
+    nw = 4096
     nw = min(nw, 4096)
     buf = np.zeros(nw * SLOTS, dtype=np.uint64)
-    rc = lib.bfir_debug_read_trace(kern, buf.ctypes.data, nw)
+    rc = (lib.bfir_debug_read_trace if kern == 2 else lib.bfir_debug_read_trace_pair)(kern, buf.ctypes.data, nw)
     assert rc == 0, rc
     t = buf.reshape(nw, SLOTS).astype(np.int64)
     order = list(ph.keys())
     t = t[(t[:, order[0]] > 0) & (t[:, order[-1]] >= t[:, order[0]])]
     t = t[t[:, order[0]] >= t[:, order[0]].max() - 100000]   # the last launch only (1 ms window)
     nw = len(t)
+    if nw == 0:
+        print('==', nm, ': no stamps'); continue
     order = list(ph.keys())
     t0 = t[:, order[0]].min()
     print(f"== {nm}: {nw} workgroups; launch span {(t[:, order[-1]].max() - t0) / 100:.1f} us; "

@@ -1,0 +1,109 @@
+"""The float fast path (csrc/pair.hip): two channels per complex transform on raw frames.
+
+It is selected for FLOAT_LE in and out, fp32 arithmetic, an even channel count and
+512 <= L <= 8192; BFIR_PAIR=0 at engine creation keeps the planar staging kernels.  Both must
+agree with the oracle (1e-5) and keep the reference's bookkeeping: time history across calls,
+chunks and reset (brutefir.cpp:255-260, 346-367), overflow statistics and the NaN verdict
+(real2raw.cpp:321-336, brutefir.cpp:316-321)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _planar_engine(bfir, *args, **kw):
+    os.environ["BFIR_PAIR"] = "0"
+    try:
+        return bfir.Brutefir(*args, **kw)
+    finally:
+        del os.environ["BFIR_PAIR"]
+
+
+def _data(orc, C, taps, frames, seed):
+    rng = np.random.default_rng(seed)
+    return orc.synth_ir(rng, C, taps, np.float32), orc.synth_audio(rng, frames, C, np.float32)
+
+
+@pytest.mark.parametrize("L,B,C,nb,chunk", [(512, 3, 2, 9, 4), (1024, 5, 6, 13, 1), (4096, 2, 8, 5, 3), (8192, 2, 2, 4, 2)])
+def test_pair_and_planar_paths_agree(orc, bfir, L, B, C, nb, chunk):
+    h, x = _data(orc, C, B * L - 11, nb * L, seed=L + C)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    outs = []
+    for make in (bfir.Brutefir, lambda *a: _planar_engine(bfir, *a)):
+        eng = make(L, B, 4, C); eng.set_chunk(chunk); assert eng.set_coeff(h) == 0
+        rc, y = eng.run(x)
+        assert rc == 0 and rel_err(y, y_ref) <= TOL[4]
+        outs.append((y, [eng.overflow(c) for c in range(C)]))
+        eng.close()
+    assert rel_err(outs[0][0], outs[1][0]) <= 2e-6          # two FFT factorizations of the same sums
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert a.n_overflows == b.n_overflows and abs(a.largest - b.largest) <= 1e-5 * max(b.largest, 1e-30)
+
+
+def test_block_by_block_equals_batched_on_the_pair_path(orc, bfir):
+    """The plug-in's pattern (foo_dsp_bfir.cpp:311-349): one run() per block; every chunk is one block,
+    so the history hand-over of one-block chunks carries the whole run."""
+    L, B, C, nb = 512, 4, 4, 11
+    h, x = _data(orc, C, 1900, nb * L, seed=8)
+    a = bfir.Brutefir(L, B, 4, C); a.set_coeff(h)
+    _, y_all = a.run(x)
+    b = bfir.Brutefir(L, B, 4, C); b.set_coeff(h)
+    parts = [b.run(x[t * L:(t + 1) * L])[1] for t in range(nb)]
+    assert np.array_equal(np.concatenate(parts), y_all)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h)
+    assert rel_err(y_all, ref.run(x)[1]) <= TOL[4]
+
+
+def test_reset_keeps_time_history_on_the_pair_path(orc, bfir):
+    """brutefir::reset clears counters only (brutefir.cpp:346-367): the first block after it still
+    sees whatever block input_timecbuf[n][0] holds -- after an odd number of blocks the one before last."""
+    L, B, C = 512, 3, 2
+    h, x = _data(orc, C, 1300, 10 * L, seed=21)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h)
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_coeff(h); eng.set_chunk(2)
+    for nblk in (3, 2, 1, 1):
+        seg = x[:nblk * L]
+        _, yr = ref.run(seg); rc, y = eng.run(seg)
+        assert rc == 0 and rel_err(y, yr) <= TOL[4]
+        ref.reset(); eng.reset()
+        x = x[nblk * L:]
+    _, yr = ref.run(x); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, yr) <= TOL[4]
+
+
+def test_overflow_statistics_and_nan_verdict_on_the_pair_path(orc, bfir):
+    L, B, C, nb = 512, 2, 4, 10
+    rng = np.random.default_rng(10)   # no |sample| within 1e-5 of the clip threshold
+    h = [np.r_[np.float32(g), np.zeros(700, np.float32)] for g in (0.5, 1.5, 3.0, 0.25)]   # pure gains
+    x = orc.synth_audio(rng, nb * L, C, np.float32)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_coeff(h); eng.set_chunk(4); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, y_ref) <= TOL[4]
+    assert np.abs(np.abs(y_ref.astype(np.float64)) - 1.0).min() > 1e-5   # nothing sits on the threshold
+    for c in range(C):
+        o, r = eng.overflow(c), ref.overflow(c)
+        assert o.n_overflows == r.n_overflows
+        assert abs(o.largest - r.largest) <= 1e-5 * r.largest
+    assert eng.overflow(0).n_overflows == 0 and eng.overflow(2).n_overflows > 0
+    # a NaN in block 1: the reference stops there with -1, the batched call reports -1 at the end
+    bad = x.copy(); bad[L + 7, 3] = np.nan
+    eng2 = bfir.Brutefir(L, B, 4, C); eng2.set_coeff(h)
+    ref2 = orc.Engine(L, B, 4, C); ref2.set_coeff(h)
+    assert ref2.run(bad)[0] == -1 and eng2.run(bad)[0] == -1
+
+
+def test_pair_path_needs_8_byte_aligned_frames(bfir):
+    import torch
+    L, B, C = 512, 2, 2
+    eng = bfir.Brutefir(L, B, 4, C)
+    eng.set_coeff([np.ones(10, np.float32)] * C)
+    buf = torch.zeros(2 * L * C + 2, device="cuda", dtype=torch.float32)
+    out = torch.zeros_like(buf)
+    with pytest.raises(bfir.BfirError):
+        eng.run_device(buf.data_ptr() + 4, out.data_ptr(), 1)
+    eng.run_device(buf.data_ptr() + 8, out.data_ptr() + 8, 1)   # aligned: fine
+    assert eng.sync() == 0

@@ -12,7 +12,9 @@ own independent 8-channel engine (weak scaling, no data-path collective).
 
 The JSON line also carries
   roofline     algorithmic HBM bytes of the dominant kernel / its mean launch
-               time (HIP events on the launch stream) against 8 TB/s
+               time (HIP events on the launch stream) against 8 TB/s; the timed
+               region overlaps three kernels, so the same figure from an untimed
+               serial-schedule pass is given beside it (*_exclusive)
   cpu_baseline the CPU oracle (a port of the reference algorithm) timed on a
                bounded sample of the same workload on this host, 1 thread.
 """
@@ -39,14 +41,16 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes_per_block(C, B, N, L, s):
-    """bytes one run() block must move, split by the kernel that moves them."""
+def algorithmic_bytes_per_block(C, B, N, L, s, fused_io=False):
+    """bytes one run() block must move, split by the kernel that moves them.
+    fused_io: the pair path has no staging kernels -- k_fwd reads the raw frames itself (its
+    window read is the same C*s*N), k_inv writes the output block."""
     return {
-        "k_stage_in": C * s * L,          # input block
-        "k_fwd": C * s * N,               # new delay-line slot
-        "k_mac": C * s * 2 * B * N,       # all partition spectra + all delay-line spectra
-        "k_inv": 0,
-        "k_stage_out": C * s * L,         # output block
+        "k_stage_in": 0 if fused_io else C * s * L,   # input block
+        "k_fwd": C * s * N,                           # [previous | new] window -> new delay-line slot
+        "k_mac": C * s * 2 * B * N,                   # all partition spectra + all delay-line spectra
+        "k_inv": C * s * L if fused_io else 0,
+        "k_stage_out": 0 if fused_io else C * s * L,  # output block
     }
 
 
@@ -193,6 +197,28 @@ def main():
         prof = eng.profile()
         eng.set_profiling(False)
 
+    # untimed extra pass for the roofline object: the same engine configuration on a serial schedule
+    exclusive = None
+    if eng is not None and rank == 0 and not args.no_kernel_events:
+        os.environ["BFIR_PIPE"] = "1"
+        try:
+            ser = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
+        finally:
+            del os.environ["BFIR_PIPE"]
+        ser.set_chunk(args.chunk)
+        for k in range(n_eng):
+            assert ser.set_coeff(hs[k], engine_index=k) == 0
+        ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=eng_stride,
+                       out_stride_bytes=eng_stride, stream=stream.cuda_stream)
+        assert ser.sync() == 0
+        ser.set_profiling(True)
+        for _ in range(2):
+            ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=eng_stride,
+                           out_stride_bytes=eng_stride, stream=stream.cuda_stream)
+        assert ser.sync() == 0
+        exclusive = ser.profile()
+        ser.close()
+
     # the job's time is the slowest rank's; its work is the sum of every rank's units
     elapsed = sharding.max_over_ranks(elapsed, red_dev)
     total_samples = sharding.sum_over_ranks(n_eng * nb * L * C * args.steps, red_dev)
@@ -200,7 +226,8 @@ def main():
 
     result = None
     if rank == 0:
-        alg = algorithmic_bytes_per_block(C, B, N, L, s)
+        fused_io = bool(prof) and prof.get("k_stage_in", (0, 0))[1] == 0
+        alg = algorithmic_bytes_per_block(C, B, N, L, s, fused_io)
         roofline = None
         if not args.no_kernel_events and any(v[1] for v in prof.values()):
             dom = max(prof, key=lambda k: prof[k][0])
@@ -214,6 +241,19 @@ def main():
                         "avg_launch_ms": round(ms / launches, 5),
                         "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)
                                             for k, v in prof.items()}}
+            # The timed region runs fwd(k+1), mac(k) and inv(k-1) concurrently on three streams, so
+            # the launch durations above are those of kernels SHARING the GPU.  One extra untimed pass
+            # on a serial schedule (BFIR_PIPE=1) gives each kernel's duration with the GPU to itself.
+            if exclusive is not None:
+                ex = {k: v[0] / max(v[1], 1) for k, v in exclusive.items() if v[1]}
+                roofline["exclusive_launch_ms"] = {k: round(v, 5) for k, v in ex.items()}
+                if dom in ex:
+                    a_ex = alg[dom] * blocks_per_launch / (ex[dom] * 1e-3) / 1e9
+                    roofline["achieved_exclusive"] = round(a_ex, 1)
+                    roofline["frac_exclusive"] = round(a_ex / HBM_PEAK_GBS, 4)
+                    t = roofline["traffic"]
+                    if t:
+                        roofline["traffic_rate_exclusive_GBs"] = round(t / (ex[dom] * 1e-3) / 1e9, 1)
         cpu = None
         parity = None
         if not args.no_cpu_baseline:

@@ -1,18 +1,21 @@
 #!/bin/bash
-# Bench lines of the non-headline BASELINE configs (parity-test cases; recorded for DESIGN.md only).
+# BASELINE.json configs other than the headline, on one GPU.
 set -o pipefail
-TAG=${1:-cfgs}
-OUT=gpurun_out/$TAG
+OUT=gpurun_out/${1:-other}
 mkdir -p $OUT
-python bench.py --workload cfg2_2ch_65536tap_L8192_fp32 --blocks 1024 --chunk 512 --steps 4 > $OUT/cfg2.json 2>$OUT/cfg2.err || tail -3 $OUT/cfg2.err
-python bench.py --workload cfg5_2ch_262144tap_L4096_fp64 --blocks 1024 --chunk 256 --steps 4 > $OUT/cfg5.json 2>$OUT/cfg5.err || tail -3 $OUT/cfg5.err
-python bench.py --workload cfg4_stereo_65536tap_L4096_fp32 --streams 32 --blocks 64 --chunk 32 --steps 4 --no-cpu-baseline > $OUT/cfg4_32streams.json 2>$OUT/cfg4.err || tail -3 $OUT/cfg4.err
-python bench.py --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 32 --chunk 16 --steps 4 --no-cpu-baseline > $OUT/cfg4_256streams.json 2>$OUT/cfg4b.err || tail -3 $OUT/cfg4b.err
-python - <<PY
-import json,glob
-for f in sorted(glob.glob("$OUT/*.json")):
-    try:
-        d=json.load(open(f)); r=d["roofline"]
-        print(f.split("/")[-1], "value", d["value"], "Msamples/s; pct_alg_roofline", d["pct_of_hbm_roofline_algorithmic"], "dom", r["kernel"], r["kernel_ms_share"], "cpu", (d["cpu_baseline"] or {}).get("value"), "parity", d["parity_rel_err_vs_oracle"])
-    except Exception as e: print(f, "ERR", e)
+run() {
+  name=$1; shift
+  timeout -k 10 600 python bench.py "$@" --steps 4 --warmup 1 --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.err || { echo "$name failed"; tail -5 $OUT/$name.err; return; }
+  python - <<PY
+import json
+d=json.load(open("$OUT/$name.json")); r=d["roofline"]
+print("%-6s %-34s %9.1f Msamples/s  %8.3f ms/step  blocks/step %d  blocks/launch %d  streams %d  shares %s" % (
+    "$name", d["config"]["workload"], d["value"], d["ms_per_step"], d["config"]["blocks_per_step"],
+    d["config"]["blocks_per_launch"], d["config"]["streams_total"], r["kernel_ms_share"]))
 PY
+}
+run cfg2 --workload cfg2_2ch_65536tap_L8192_fp32 --blocks 4096 --chunk 1024
+run cfg4 --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64 --chunk 64
+run cfg5 --workload cfg5_2ch_262144tap_L4096_fp64 --blocks 2048 --chunk 512
+run cfg3g --workload cfg3_8ch_131072tap_L4096_fp32        # headline again, for the same box
+BFIR_PAIR=0 run cfg3_general_path --workload cfg3_8ch_131072tap_L4096_fp32

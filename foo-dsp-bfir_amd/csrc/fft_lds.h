@@ -261,22 +261,55 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
         return (tid + (e / R) * NT) + Dft<R, SIGN, T>::inv(e % R) * (M / R);
     }
 
+    // twiddles of pass S for this thread: (P/R) butterflies x (R-1) factors
+    template <int S> static constexpr int ntw() { return S == 0 ? 1 : (P / radix(S)) * (radix(S) - 1); }
+
+    // Fetch the twiddles of pass S.  Called BEFORE the exchange that feeds pass S (they do not
+    // depend on the data), so the L2 latency of these loads hides behind the barriers and LDS
+    // traffic of the exchange instead of stalling the first butterfly of the pass.
     template <int S>
-    __device__ __forceinline__ static void butterflies(T *re, T *im, const V2 *__restrict__ tw, int tid)
+    __device__ __forceinline__ static void load_twiddles(V2 (&w)[ntw<S>()], const V2 *__restrict__ tw, int tid)
+    {
+        constexpr int R = radix(S), p = pprod(S);
+#pragma unroll
+        for (int b = 0; b < P / R; b++) {
+            const int k = (tid + b * NT) & (p - 1);
+#pragma unroll
+            for (int r = 1; r < R; r++) w[b * (R - 1) + r - 1] = tw[twoff(S) + (r - 1) * p + k];
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ static void butterflies(T *re, T *im, const V2 (&w)[ntw<S>()])
     {
         constexpr int R = radix(S), p = pprod(S);
 #pragma unroll
         for (int b = 0; b < P / R; b++) {
             if constexpr (p > 1) {
-                const int k = (tid + b * NT) & (p - 1);
 #pragma unroll
                 for (int r = 1; r < R; r++) {
-                    V2 w = tw[twoff(S) + (r - 1) * p + k];
-                    cmul(re[b * R + r], im[b * R + r], w.x, (T)(SIGN < 0 ? w.y : -w.y));
+                    const V2 ww = w[b * (R - 1) + r - 1];
+                    cmul(re[b * R + r], im[b * R + r], ww.x, (T)(SIGN < 0 ? ww.y : -ww.y));
                 }
             }
             Dft<R, SIGN, T>::run(re + b * R, im + b * R);
         }
+    }
+
+    // one pass after the first: twiddle fetch, exchange, butterflies.  fp64 transforms have no
+    // registers to spare for the early fetch (data alone is 2 x 2P registers), they load late.
+    template <int S>
+    __device__ __forceinline__ static void pass(T *re, T *im, V2 *lds, const V2 *__restrict__ tw, int tid)
+    {
+        V2 w[ntw<S>()];
+        if constexpr (sizeof(T) == 4) {
+            load_twiddles<S>(w, tw, tid);
+            exchange<S - 1>(re, im, lds, tid);
+        } else {
+            exchange<S - 1>(re, im, lds, tid);
+            load_twiddles<S>(w, tw, tid);
+        }
+        butterflies<S>(re, im, w);
     }
 
     // write the outputs of pass S to LDS and fetch the inputs of pass S+1
@@ -311,11 +344,14 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     __device__ __forceinline__ static void run(T *re, T *im, V2 *lds, const V2 *__restrict__ tw, int tid)
     {
         constexpr int TK = SIGN < 0 ? 0 : 1;   // trace array: forward / inverse
-        butterflies<0>(re, im, tw, tid);
+        {
+            V2 w0[1];
+            butterflies<0>(re, im, w0);
+        }
         BFIR_STAMP(TK, 2);
-        if constexpr (NP > 1) { exchange<0>(re, im, lds, tid); BFIR_STAMP(TK, 3); butterflies<1>(re, im, tw, tid); BFIR_STAMP(TK, 4); }
-        if constexpr (NP > 2) { exchange<1>(re, im, lds, tid); BFIR_STAMP(TK, 5); butterflies<2>(re, im, tw, tid); BFIR_STAMP(TK, 6); }
-        if constexpr (NP > 3) { exchange<2>(re, im, lds, tid); BFIR_STAMP(TK, 7); butterflies<3>(re, im, tw, tid); BFIR_STAMP(TK, 8); }
+        if constexpr (NP > 1) { pass<1>(re, im, lds, tw, tid); BFIR_STAMP(TK, 4); }
+        if constexpr (NP > 2) { pass<2>(re, im, lds, tw, tid); BFIR_STAMP(TK, 6); }
+        if constexpr (NP > 3) { pass<3>(re, im, lds, tw, tid); BFIR_STAMP(TK, 8); }
         (void)TK;
     }
 };

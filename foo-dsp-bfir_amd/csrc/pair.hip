@@ -43,6 +43,10 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_fwd_pair(FwdPairArgs a, c
     using F = LdsFft<float, LOG2N, -1>;
     constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2;
     __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
+#ifdef BFIR_PAIR_LDS_PAD   // occupancy experiment: extra LDS so that fewer workgroups fit a CU
+    __shared__ volatile float occ_pad[BFIR_PAIR_LDS_PAD / 4];
+    if (a.n_t < 0) { occ_pad[threadIdx.x] = 1.f; a.scale += occ_pad[threadIdx.x ^ 1]; }
+#endif
 
     const int tid = threadIdx.x;
     const int w = xcd_remap();
@@ -110,6 +114,10 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
     constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2;
     __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
     __shared__ unsigned int red_max[NT / 64 > 0 ? NT / 64 : 1][2], red_cnt[NT / 64 > 0 ? NT / 64 : 1][2];
+#ifdef BFIR_PAIR_LDS_PAD
+    __shared__ volatile float occ_pad[BFIR_PAIR_LDS_PAD / 4];
+    if (a.n_t < 0) { occ_pad[threadIdx.x] = 1.f; a.scale += occ_pad[threadIdx.x ^ 1]; }
+#endif
 
     const int tid = threadIdx.x;
     const int w = xcd_remap();

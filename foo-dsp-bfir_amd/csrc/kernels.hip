@@ -835,8 +835,6 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         if (lds_ok && (v == 0 || v == 8)) launch_mac_lds<8>(a, s);
         else if (lds_ok && v == 6) launch_mac_lds<4>(a, s);
         else if (lds_ok && v == 7) launch_mac_lds<2>(a, s);
-        else if (tt >= 16 && v == 2) launch_mac_t<float, 16, 1, 2>(a, s);
-        else if (tt >= 16 && v == 3) launch_mac_t<float, 16, 1, 4>(a, s);
         else if (tt >= 8 && v == 1) launch_mac_t<float, 8, 2, 1>(a, s);
         else if (tt >= 4 && v == 4) launch_mac_t<float, 4, 3, 2>(a, s);
         else if (tt >= 8) launch_mac_t<float, 8, 2, 2>(a, s);   // measured best (profiles/r01_mac_variants.txt)

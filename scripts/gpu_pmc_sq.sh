@@ -15,7 +15,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        for n in ("k_mac_lds","k_mac","k_fwd","k_inv","k_stage_in","k_stage_out"):
+        for n in ("k_mac","k_fwd","k_inv","k_stage_in","k_stage_out"):
             if n in k: k=n; break
         else: continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -524,7 +524,6 @@ __device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], fl
     for (int d = 0; d < D; d++) { BFIR_DUTY_ADVANCE(); q[(1 + d) % D] = BFIR_DUTY_LOAD(); }   // steps 1 .. D
     __syncthreads();
     for (int i0 = 0; i0 < nb; i0 += 8) {
-        BFIR_STAMP(2, 2 + (i0 >> 3 < 6 ? i0 >> 3 : 6));
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
             const int i = i0 + ii;
@@ -577,8 +576,6 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     const int nb = a.nblk[gc];
     const int ring = a.ring;
     const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
-
-    BFIR_STAMP(2, 0);
     v4f accr[8], acci[8], wr[8], wi[8];
     float dc[8], ny[8];
 #pragma unroll
@@ -589,7 +586,6 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
         wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
         s_ring[8 * wv + j][0][lane] = wr[j]; s_ring[8 * wv + j][1][lane] = wi[j];
     }
-    BFIR_STAMP(2, 1);
     const bool duty_is_h = wv < 2;
     const int plane = wv & 1;
     if (bt == 0)
@@ -598,7 +594,6 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     else
         mac_lds_steps<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
                                 nb, ring, sl_tb, lane, wv);
-    BFIR_STAMP(2, 9);
     float *__restrict__ Y = (float *)a.y + (long)gc * a.y_ch_stride;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -609,7 +604,6 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
             yo[0] = accr[j]; yo[1] = acci[j];
         }
     }
-    BFIR_STAMP(2, 10);
 }
 
 // ---------------------------------------------------------------------------

@@ -104,6 +104,8 @@ def main():
                     help="total independent engines dealt out to the ranks (0 = one per rank); "
                          "configs[3]: --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exclusive-pass", action="store_true",
+                    help="skip the untimed serial-schedule pass (rocprofv3 runs: keeps the kernel trace to the overlapped schedule)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -199,7 +201,7 @@ def main():
 
     # untimed extra pass for the roofline object: the same engine configuration on a serial schedule
     exclusive = None
-    if eng is not None and rank == 0 and not args.no_kernel_events:
+    if eng is not None and rank == 0 and not args.no_kernel_events and not args.no_exclusive_pass:
         os.environ["BFIR_PIPE"] = "1"
         try:
             ser = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)

@@ -25,7 +25,7 @@ for l in open("$OUT/bench_sweep.jsonl"):
     d=json.loads(l); r=d["roofline"]; print(d["config"]["blocks_per_launch"], d["value"], r["kernel_ms_share"], r["kernel"], r["avg_launch_ms"])
 PY
 echo "== rocprof kernel stats" | tee -a $OUT/progress.log
-CMD="python bench.py --chunk $CHUNK --steps 4 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --chunk $CHUNK --steps 4 --warmup 1 --no-cpu-baseline --no-exclusive-pass"
 echo "{\"workload\": \"$WORKLOAD\", \"chunk\": $CHUNK, \"command\": \"$CMD\"}" > $OUT/pmc_meta.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- $CMD > $OUT/rocprof_stats.log 2>&1 || { tail -20 $OUT/rocprof_stats.log; exit 1; }
 echo "== rocprof pmc FETCH_SIZE" | tee -a $OUT/progress.log

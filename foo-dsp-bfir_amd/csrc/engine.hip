@@ -257,7 +257,9 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     e->of_max = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format) - 1.0;
     {   // BFIR_MAC_VARIANT != 0 (tuning aid) keeps the grouped layout and the other MAC kernels
         const char *mv = getenv("BFIR_MAC_VARIANT");
-        e->ilv = realsize == 4 && e->N >= 512 && e->B <= 32 && !(mv && atoi(mv) != 0);
+        // B <= 96: up to three register batches of the streaming MAC; beyond that the extra passes over X
+        // and Y cost more than the LDS-shared kernel of the grouped layout (profiles/r01_other_configs.txt)
+        e->ilv = realsize == 4 && e->N >= 512 && e->B <= 96 && !(mv && atoi(mv) != 0);
     }
     {   // BFIR_PAIR=0 (tuning aid) keeps the planar staging kernels
         const char *pv = getenv("BFIR_PAIR");

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
 }
 
 // ---------------------------------------------------------------------------
-// k_mac_stream: the time-streaming form of the same sums (fp32, B <= PB)
+// k_mac_stream: the time-streaming form of the same sums (fp32; B > PB in batches of PB partitions)
 // ---------------------------------------------------------------------------
 // One lane owns ONE bin of one channel for a range of output blocks and keeps
 // all PB filter partitions of that bin (2 PB registers) plus PB rotating
@@ -637,11 +637,14 @@ template <int LO, int HI, typename F> __device__ __forceinline__ void static_for
     }
 }
 
-template <int PB, int D, int MODE>
+// ACC (partition batches after the first, B > PB): the sums continue from the partial results the
+// previous batch left in Y; those are fetched D blocks ahead like the spectra (yq, ty_next).
+template <int PB, int D, int MODE, bool ACC>
 __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB], const float (&hr)[PB],
-                                                 const float (&hi)[PB], float2 (&q)[D],
+                                                 const float (&hi)[PB], float2 (&q)[D], float2 (&yq)[ACC ? D : 1],
                                                  const float2 *__restrict__ Xc, float2 *__restrict__ Yc, unsigned k,
-                                                 int N2, int ring, int &sq, int tg, int n_t, bool store_lane)
+                                                 int N2, int ring, int &sq, int &ty_next, int tg, int n_t,
+                                                 bool store_lane)
 {
     static_assert(PB % D == 0, "queue depth must divide the group");
     constexpr int NU = MODE == 2 ? PB - 1 : PB;          // the block PB before the range feeds nothing
@@ -652,12 +655,20 @@ __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB
         sq -= 1; if (sq < 0) sq += ring;
         const float nxi = -xi;
         constexpr int plo = MODE == 2 ? u + 1 : 0, phi = MODE == 0 ? u : PB - 1;
+        float y0r = 0.f, y0i = 0.f;                      // what the sums of y[t] start from
+        if constexpr (ACC && plo == 0) {
+            y0r = yq[u % D].x; y0i = yq[u % D].y;
+            float2 v; v.x = 0.f; v.y = 0.f;
+            if (ty_next >= 0 && ty_next < n_t) v = (Yc + (long)ty_next * N2)[k];
+            yq[u % D] = v;
+            ty_next -= 1;
+        }
         static_for<plo, phi + 1>([&](auto P) {
             constexpr int p = decltype(P)::value;
             constexpr int sl = (PB - 1 - u + p) % PB;    // accumulator of y[t + p]
             if constexpr (p == 0) {
-                ar[sl] = fmaf(xr, hr[0], 0.f); ar[sl] = fmaf(nxi, hi[0], ar[sl]);
-                ai[sl] = fmaf(xr, hi[0], 0.f); ai[sl] = fmaf(xi, hr[0], ai[sl]);
+                ar[sl] = fmaf(xr, hr[0], y0r); ar[sl] = fmaf(nxi, hi[0], ar[sl]);
+                ai[sl] = fmaf(xr, hi[0], y0i); ai[sl] = fmaf(xi, hr[0], ai[sl]);
             } else {
                 ar[sl] = fmaf(xr, hr[p], ar[sl]); ar[sl] = fmaf(nxi, hi[p], ar[sl]);
                 ai[sl] = fmaf(xr, hi[p], ai[sl]); ai[sl] = fmaf(xi, hr[p], ai[sl]);
@@ -677,8 +688,8 @@ __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB
     });
 }
 
-template <int PB, int D>
-__global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int nR, int ngrp, int n_dc)
+template <int PB, int D, bool ACC>
+__global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int ncol, int nR, int ngrp, int n_dc, int p0)
 {
     const int N = a.N, ring = a.ring;
     if ((int)blockIdx.x < n_dc) {
@@ -692,24 +703,30 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
         const float *__restrict__ X = (const float *)a.x + (long)gc * a.x_ch_stride;
         const float *__restrict__ H = (const float *)a.h + (long)gc * a.h_ch_stride;
         const int nb = a.nblk[gc];
-        for (int i = threadIdx.x; i < 256 + PB - 1; i += 256) {      // s_x[.][i] = block t0 - (PB-1) + i
-            int sl = (a.base_slot + t0 - (PB - 1) + i) % ring; if (sl < 0) sl += ring;
-            s_x[0][i] = X[(long)sl * N]; s_x[1][i] = X[(long)sl * N + 1];
-        }
-        if (threadIdx.x < PB) {
-            const int p = threadIdx.x;
-            s_hh[0][p] = p < nb ? H[(long)p * N] : 0.f; s_hh[1][p] = p < nb ? H[(long)p * N + 1] : 0.f;
-        }
-        __syncthreads();
         const int t = t0 + threadIdx.x;
-        if (t >= a.n_t) return;
         float dc = 0.f, ny = 0.f;
-        for (int p = 0; p < nb; p++) {
-            dc = fmaf(s_x[0][threadIdx.x + PB - 1 - p], s_hh[0][p], dc);
-            ny = fmaf(s_x[1][threadIdx.x + PB - 1 - p], s_hh[1][p], ny);
+        for (int pb0 = 0; pb0 < nb; pb0 += PB) {                     // all partitions, PB at a time, in order
+            if (pb0 > 0) __syncthreads();
+            for (int i = threadIdx.x; i < 256 + PB - 1; i += 256) {  // s_x[.][i] = block t0 - pb0 - (PB-1) + i
+                int sl = (a.base_slot + t0 - pb0 - (PB - 1) + i) % ring; if (sl < 0) sl += ring;
+                s_x[0][i] = X[(long)sl * N]; s_x[1][i] = X[(long)sl * N + 1];
+            }
+            if (threadIdx.x < PB) {
+                const int p = pb0 + threadIdx.x;
+                s_hh[0][threadIdx.x] = p < nb ? H[(long)p * N] : 0.f;
+                s_hh[1][threadIdx.x] = p < nb ? H[(long)p * N + 1] : 0.f;
+            }
+            __syncthreads();
+            const int np = min(PB, nb - pb0);
+            for (int p = 0; p < np; p++) {
+                dc = fmaf(s_x[0][threadIdx.x + PB - 1 - p], s_hh[0][p], dc);
+                ny = fmaf(s_x[1][threadIdx.x + PB - 1 - p], s_hh[1][p], ny);
+            }
         }
-        float *yo = (float *)a.y + (long)gc * a.y_ch_stride + (long)t * N;
-        yo[0] = dc; yo[1] = ny;
+        if (t < a.n_t) {
+            float *yo = (float *)a.y + (long)gc * a.y_ch_stride + (long)t * N;
+            yo[0] = dc; yo[1] = ny;
+        }
         return;
     }
     // XCD-aware bijective remap (see k_mac): (channel, bin column) major, time range minor
@@ -730,7 +747,8 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     BFIR_STAMP(2, 0);
 
     float2 q[D];
-    int sq = (a.base_slot + ta + R - 1) % ring;          // newest block of the range first
+    // newest block of the range first; batch p0 pairs output t with spectrum t - p0 - p
+    int sq = ((a.base_slot + ta + R - 1 - p0) % ring + ring) % ring;
 #pragma unroll
     for (int d = 0; d < D; d++) {
         q[d] = (Xc + (long)sq * N2)[k];
@@ -739,8 +757,19 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     float hr[PB], hi[PB];
 #pragma unroll
     for (int p = 0; p < PB; p++) {
-        if (p < nb) { const float2 h = (Hc + (long)p * N2)[k]; hr[p] = h.x; hi[p] = h.y; }
+        if (p0 + p < nb) { const float2 h = (Hc + (long)(p0 + p) * N2)[k]; hr[p] = h.x; hi[p] = h.y; }
         else { hr[p] = 0.f; hi[p] = 0.f; }
+    }
+    float2 yq[ACC ? D : 1];
+    int ty_next = ta + R - 1;
+    if constexpr (ACC) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            float2 v; v.x = 0.f; v.y = 0.f;
+            if (ty_next >= 0 && ty_next < a.n_t) v = (Yc + (long)ty_next * N2)[k];
+            yq[d] = v;
+            ty_next -= 1;
+        }
     }
     float ar[PB], ai[PB];
 #pragma unroll
@@ -748,15 +777,15 @@ __global__ __launch_bounds__(256, 3) void k_mac_stream(MacArgs a, int ncol, int 
     const bool store_lane = k != 0;
     int tg = ta + R - PB;
     BFIR_STAMP(2, 1);
-    mac_stream_group<PB, D, 0>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 0, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
     BFIR_STAMP(2, 2);
     for (int g = my_grp - 2; g >= 0; g--) {
         tg -= PB;
-        mac_stream_group<PB, D, 1>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
+        mac_stream_group<PB, D, 1, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
     }
     BFIR_STAMP(2, 3);
     tg -= PB;
-    mac_stream_group<PB, D, 2>(ar, ai, hr, hi, q, Xc, Yc, k, N2, ring, sq, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 2, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
     BFIR_STAMP(2, 4);
 }
 
@@ -777,7 +806,13 @@ template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStre
     }
     const int R = ngrp * PB, nR = (a.n_t + R - 1) / R;
     const int n_dc = a.n_ch * ((a.n_t + 255) / 256);
-    hipLaunchKernelGGL((k_mac_stream<PB, D>), dim3(n_dc + nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, ngrp, n_dc);
+    hipLaunchKernelGGL((k_mac_stream<PB, D, false>), dim3(n_dc + nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, ngrp,
+                       n_dc, 0);
+    // more partitions than fit the registers: further batches of PB continue the sums left in Y
+    // (same stream, so batch b sees batch b-1's stores; DC/Nyquist were finished by the first launch)
+    for (int p0 = PB; p0 < a.B; p0 += PB)
+        hipLaunchKernelGGL((k_mac_stream<PB, D, true>), dim3(nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, ngrp, 0,
+                           p0);
 }
 
 template <int D> static void launch_mac_lds(const MacArgs &a, hipStream_t s)
@@ -816,9 +851,9 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     const int tt = a.n_t;
     if (a.realsize == 4) {
         const int v = mac_variant();
-        // time-streaming kernel: every partition of a bin in registers (B <= 32), whole 256-bin columns
+        // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns
         const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
-        if (a.interleaved) {                          // the engine picked the pair layout: N >= 512, B <= 32
+        if (a.interleaved) {                          // the engine picked the pair layout (fp32, N >= 512)
             if (pb == 4) launch_mac_stream<4, 4>(a, s);
             else if (pb == 8) launch_mac_stream<8, 8>(a, s);
             else if (pb == 16) launch_mac_stream<16, 8>(a, s);

@@ -107,3 +107,31 @@ def test_pair_path_needs_8_byte_aligned_frames(bfir):
         eng.run_device(buf.data_ptr() + 4, out.data_ptr(), 1)
     eng.run_device(buf.data_ptr() + 8, out.data_ptr() + 8, 1)   # aligned: fine
     assert eng.sync() == 0
+
+
+@pytest.mark.parametrize("L,B,C,nb,chunk", [(1024, 40, 2, 50, 16), (512, 70, 3, 80, 32), (1024, 33, 4, 37, 5)])
+def test_more_partitions_than_one_register_batch(orc, bfir, L, B, C, nb, chunk):
+    """B > 32: the streaming MAC runs in batches of 32 partitions that continue the sums left in Y
+    (the plug-in's own shape: FILTER_LEN 1024 and as many partitions as the impulse needs)."""
+    h, x = _data(orc, C, B * L - 5, nb * L, seed=B + C)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_chunk(chunk); assert eng.set_coeff(h) == 0
+    rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, y_ref) <= TOL[4]
+    # chunking stays bit-exact across the batches
+    eng2 = bfir.Brutefir(L, B, 4, C); eng2.set_chunk(nb); eng2.set_coeff(h)
+    assert np.array_equal(eng2.run(x)[1], y)
+    # and the batched sums are the very sums of the grouped-layout MAC kernels (general path for both)
+    os.environ["BFIR_PAIR"] = "0"
+    try:
+        a = bfir.Brutefir(L, B, 4, C)
+        os.environ["BFIR_MAC_VARIANT"] = "8"
+        try:
+            b = bfir.Brutefir(L, B, 4, C)
+        finally:
+            del os.environ["BFIR_MAC_VARIANT"]
+    finally:
+        del os.environ["BFIR_PAIR"]
+    for e in (a, b):
+        e.set_chunk(chunk); e.set_coeff(h)
+    assert np.array_equal(a.run(x)[1], b.run(x)[1])

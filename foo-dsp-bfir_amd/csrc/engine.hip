@@ -119,7 +119,7 @@ struct bfir_engine {
     hipEvent_t ev_inv[2] = {nullptr, nullptr};
     bool pipe3 = true;                     // BFIR_PIPE=2: MAC on the caller's stream (two-stage schedule)
     // spectra (X, H, Y) as (re, im) pairs instead of the reference's 4 re | 4 im groups: the layout
-    // of the fp32 streaming MAC kernel; chosen once per engine (N >= 512, B <= 32, fp32)
+    // of the fp32 streaming MAC kernel; chosen once per engine (N >= 512, B <= 96, fp32)
     bool ilv = false;
     // pair path (pair.hip): FLOAT_LE in and out, even channel count, 512 <= L <= 8192 on top of ilv.
     // No planar time buffers; the engine's time history is the raw frames of the last two blocks,

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "../../include/bfir_hip.h"
@@ -725,6 +726,25 @@ extern "C" int bfir_engine_sync(bfir_engine *e)
     return BFIR_OK;
 }
 
+// memcpy between the caller's (pageable) buffers and the pinned staging buffers, split over a few
+// threads when it is large: one core moves ~9 GB/s, the host link 63 GB/s.
+static void copy_host(void *dst, const void *src, size_t n)
+{
+    constexpr size_t kMinPerThread = 4u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / kMinPerThread);
+    if (nt <= 1) { memcpy(dst, src, n); return; }
+    const size_t per = ((n / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nt; i++) {
+        const size_t o = i * per;
+        if (o >= n) break;
+        th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, std::min(per, n - o)); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (auto &t : th) t.join();
+}
+
 static int ensure_staging(bfir_engine *e)
 {
     const size_t bin = (size_t)e->n_eng * e->chunk * e->L * e->C * e->in_bytes;
@@ -767,7 +787,7 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
         HIP_TRY(hipEventSynchronize(e->ev_d2h[b]));
         const size_t per = (size_t)tc * e->L * fout;
         for (int g = 0; g < e->n_eng; g++)
-            memcpy((char *)outbuf + g * eng_out + (size_t)c0 * e->L * fout, (char *)e->pin_out[b] + g * per, per);
+            copy_host((char *)outbuf + g * eng_out + (size_t)c0 * e->L * fout, (char *)e->pin_out[b] + g * per, per);
         return BFIR_OK;
     };
     for (int k = 0; k < nchunks; k++) {
@@ -775,7 +795,7 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
         if (k >= 2) { rc = copy_out(k - 2); if (rc != BFIR_OK) return rc; }
         const size_t per_in = (size_t)tc * e->L * fin, per_out = (size_t)tc * e->L * fout;
         for (int g = 0; g < e->n_eng; g++)
-            memcpy((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
+            copy_host((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
         HIP_TRY(hipMemcpyAsync(e->dev_in[b], e->pin_in[b], per_in * e->n_eng, hipMemcpyHostToDevice, e->s_in));
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->s_in));
         rc = run_chunk(e, e->dev_in[b], (long)per_in, e->dev_out[b], (long)per_out, 0, tc, c0, e->stream,

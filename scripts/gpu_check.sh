@@ -3,7 +3,7 @@
 # Usage (from the repo root, through gpurun):  bash scripts/gpu_check.sh [tag] [chunk]
 set -o pipefail
 TAG=${1:-r01}
-CHUNK=${2:-2048}
+CHUNK=${2:-4096}
 WORKLOAD=cfg3_8ch_131072tap_L4096_fp32
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -16,7 +16,7 @@ echo "== bench default" | tee -a $OUT/progress.log
 timeout -k 10 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo bench failed; tail -20 $OUT/bench_default.err; exit 1; }
 cat $OUT/bench_default.json
 echo "== chunk sweep" | tee -a $OUT/progress.log
-for c in ${SWEEP:-256 512 1024}; do
+for c in ${SWEEP:-512 1024 2048}; do
   timeout -k 10 300 python bench.py --chunk $c --steps 4 --warmup 1 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench_sweep.err || exit 1
 done
 python - <<PY

@@ -47,11 +47,11 @@ WORKLOADS = {
 
 def algorithmic_bytes_per_block(C, B, N, L, s, fused_io=False):
     """bytes one run() block must move, split by the kernel that moves them.
-    fused_io: the pair path has no staging kernels -- k_fwd reads the raw frames itself (its
-    window read is the same C*s*N), k_inv writes the output block."""
+    fused_io: the pair path has no staging kernels -- k_fwd reads the input block itself, k_inv
+    writes the output block; the sum stays C*s*(2BN + N + 2L)."""
     return {
         "k_stage_in": 0 if fused_io else C * s * L,   # input block
-        "k_fwd": C * s * N,                           # [previous | new] window -> new delay-line slot
+        "k_fwd": C * s * (N + L) if fused_io else C * s * N,   # new delay-line slot (+ the input block)
         "k_mac": C * s * 2 * B * N,                   # all partition spectra + all delay-line spectra
         "k_inv": C * s * L if fused_io else 0,
         "k_stage_out": 0 if fused_io else C * s * L,  # output block
@@ -252,6 +252,17 @@ def main():
                         "avg_launch_ms": round(ms / launches, 5),
                         "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)
                                             for k, v in prof.items()}}
+            # the same figures for every kernel of the path (the dominant one is repeated above)
+            per = {}
+            for kname, (kms, kl) in prof.items():
+                if not kl:
+                    continue
+                bpl = n_eng * args.steps * nb / kl
+                ach = alg[kname] * bpl / (kms / kl * 1e-3) / 1e9
+                per[kname] = {"avg_launch_ms": round(kms / kl, 5), "algorithmic_bytes_per_launch": int(alg[kname] * bpl),
+                              "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "traffic": measured_traffic(kname, args.workload, args.chunk)}
+            roofline["kernels"] = per
             # The timed region runs fwd(k+1), mac(k) and inv(k-1) concurrently on three streams, so
             # the launch durations above are those of kernels SHARING the GPU.  One extra untimed pass
             # on a serial schedule (BFIR_PIPE=1) gives each kernel's duration with the GPU to itself.
@@ -265,6 +276,13 @@ def main():
                     t = roofline["traffic"]
                     if t:
                         roofline["traffic_rate_exclusive_GBs"] = round(t / (ex[dom] * 1e-3) / 1e9, 1)
+                for kname, v in per.items():
+                    if kname in ex:
+                        v["exclusive_launch_ms"] = round(ex[kname], 5)
+                        v["frac_exclusive"] = round(alg[kname] * (n_eng * args.steps * nb / prof[kname][1])
+                                                    / (ex[kname] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                        if v["traffic"]:
+                            v["traffic_rate_exclusive_GBs"] = round(v["traffic"] / (ex[kname] * 1e-3) / 1e9, 1)
         cpu = None
         parity = None
         if not args.no_cpu_baseline:

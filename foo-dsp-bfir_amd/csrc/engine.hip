@@ -97,7 +97,7 @@ struct bfir_engine {
     double in_scale = 1.0, out_scale = 1.0, of_max = 1.0;
     FftPlan plan;
     int chunk = 0, ring = 0;        // allocated geometry
-    int want_chunk = 1024;                 // blocks per launch (bfir_engine_set_chunk); buffers are sized lazily
+    int want_chunk = 0;                    // blocks per launch (bfir_engine_set_chunk); 0 = automatic; buffers are sized lazily
     void *H = nullptr, *X = nullptr, *Y = nullptr, *tout = nullptr;
     void *tin[2] = {nullptr, nullptr};
     void *Yb[2] = {nullptr, nullptr};      // product spectra, one buffer per chunk parity
@@ -353,7 +353,7 @@ extern "C" int bfir_engine_is_initialized(const bfir_engine *e)
 
 extern "C" int bfir_engine_set_chunk(bfir_engine *e, int blocks_per_launch)
 {
-    if (!e || blocks_per_launch < 1) return BFIR_ERR_ARG;
+    if (!e || blocks_per_launch < 0) return BFIR_ERR_ARG;   // 0: automatic (the default)
     e->want_chunk = blocks_per_launch;
     return BFIR_OK;
 }
@@ -683,7 +683,14 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
 
 static int ensure_chunk(bfir_engine *e, int n_blocks)
 {
-    const int want = std::max(1, std::min(e->want_chunk, n_blocks));
+    // automatic: 4096 blocks per launch (measured best for long jobs, profiles/r01_bench_chunk_sweep.jsonl),
+    // less when the delay line of that many blocks would pass 4 GiB (many channels or engines)
+    int limit = e->want_chunk;
+    if (limit <= 0) {
+        const long slots = (long)((4ull << 30) / ((size_t)e->GC * cbuf_bytes(e)));
+        limit = (int)std::max(16L, std::min(4096L, (slots - e->B) / 2));
+    }
+    const int want = std::max(1, std::min(limit, n_blocks));
     if (want > e->chunk) return alloc_work(e, want);
     return BFIR_OK;
 }
@@ -745,10 +752,14 @@ static void copy_host(void *dst, const void *src, size_t n)
     for (auto &t : th) t.join();
 }
 
+// Host-path chunk: the link, not the GPU, bounds this path, so the pinned staging buffers stay small.
+static int host_chunk(const bfir_engine *e) { return std::min(e->chunk, 512); }
+
 static int ensure_staging(bfir_engine *e)
 {
-    const size_t bin = (size_t)e->n_eng * e->chunk * e->L * e->C * e->in_bytes;
-    const size_t bout = (size_t)e->n_eng * e->chunk * e->L * e->C * e->out_bytes;
+    const int hc = host_chunk(e);
+    const size_t bin = (size_t)e->n_eng * hc * e->L * e->C * e->in_bytes;
+    const size_t bout = (size_t)e->n_eng * hc * e->L * e->C * e->out_bytes;
     if (e->stage_bytes_in >= bin && e->stage_bytes_out >= bout) return BFIR_OK;
     for (int i = 0; i < 2; i++) {
         if (e->pin_in[i]) (void)hipHostFree(e->pin_in[i]);
@@ -775,15 +786,16 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
     if (!bfir_engine_is_initialized(e)) return BFIR_ERR_STATE;
     if (n_blocks == 0) return BFIR_OK;
     HIP_TRY(hipSetDevice(e->device));
-    int rc = ensure_chunk(e, n_blocks);
+    int rc = ensure_chunk(e, std::min(n_blocks, 512));   // see host_chunk()
     if (rc != BFIR_OK) return rc;
     rc = ensure_staging(e);
     if (rc != BFIR_OK) return rc;
     const size_t fin = (size_t)e->C * e->in_bytes, fout = (size_t)e->C * e->out_bytes;  // bytes per frame
     const size_t eng_in = (size_t)n_blocks * e->L * fin, eng_out = (size_t)n_blocks * e->L * fout;
-    const int nchunks = (n_blocks + e->chunk - 1) / e->chunk;
+    const int hc = host_chunk(e);
+    const int nchunks = (n_blocks + hc - 1) / hc;
     auto copy_out = [&](int k) -> int {
-        const int b = k & 1, c0 = k * e->chunk, tc = std::min(e->chunk, n_blocks - c0);
+        const int b = k & 1, c0 = k * hc, tc = std::min(hc, n_blocks - c0);
         HIP_TRY(hipEventSynchronize(e->ev_d2h[b]));
         const size_t per = (size_t)tc * e->L * fout;
         for (int g = 0; g < e->n_eng; g++)
@@ -791,7 +803,7 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
         return BFIR_OK;
     };
     for (int k = 0; k < nchunks; k++) {
-        const int b = k & 1, c0 = k * e->chunk, tc = std::min(e->chunk, n_blocks - c0);
+        const int b = k & 1, c0 = k * hc, tc = std::min(hc, n_blocks - c0);
         if (k >= 2) { rc = copy_out(k - 2); if (rc != BFIR_OK) return rc; }
         const size_t per_in = (size_t)tc * e->L * fin, per_out = (size_t)tc * e->L * fout;
         for (int g = 0; g < e->n_eng; g++)

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
         T orr = (T)0.5 * (im[e] + pz.y), oi = (T)-0.5 * (re[e] - pz.x);
         T tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
         T xr = er + tr, xi = ei + ti;
-        if (k == 0) xi = re[e] - im[e];  // slot 4 carries Re X_{N/2}
+        if (k == 0) xi = re[e] - im[e];  // the imaginary slot of bin 0 carries Re X_{N/2} (slot 4 of group 0 in the grouped layout)
         re[e] = xr * os; im[e] = xi * os;
     }
     pin_registers(re, im);   // every Z[M-k] read happens before the barrier
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int 
 {
     const int N = a.N, ring = a.ring;
     if ((int)blockIdx.x < n_dc) {
-        // DC / Nyquist: slots 0 and 4 of group 0, two independent real sums in partition order.
+        // DC / Nyquist: the two floats of bin 0 (pairs layout), two independent real sums in partition order.
         // One workgroup = one channel x 256 output blocks: the 256+PB-1 delay-line values and the
         // PB filter values go through LDS in one round of (scattered, but concurrent) loads, then
         // every thread runs its own chain out of LDS.

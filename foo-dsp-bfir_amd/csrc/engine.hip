@@ -120,7 +120,7 @@ struct bfir_engine {
     hipEvent_t ev_inv[2] = {nullptr, nullptr};
     bool pipe3 = true;                     // BFIR_PIPE=2: MAC on the caller's stream (two-stage schedule)
     // spectra (X, H, Y) as (re, im) pairs instead of the reference's 4 re | 4 im groups: the layout
-    // of the fp32 streaming MAC kernel; chosen once per engine (N >= 512, B <= 96, fp32)
+    // of the fp32 fast MAC kernels; chosen once per engine (N >= 512, fp32)
     bool ilv = false;
     // pair path (pair.hip): FLOAT_LE in and out, even channel count, 512 <= L <= 8192 on top of ilv.
     // No planar time buffers; the engine's time history is the raw frames of the last two blocks,
@@ -258,9 +258,7 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     e->of_max = fmt_info(out_format).isfloat ? 1.0 : fmt_full_scale(out_format) - 1.0;
     {   // BFIR_MAC_VARIANT != 0 (tuning aid) keeps the grouped layout and the other MAC kernels
         const char *mv = getenv("BFIR_MAC_VARIANT");
-        // B <= 96: up to three register batches of the streaming MAC; beyond that the extra passes over X
-        // and Y cost more than the LDS-shared kernel of the grouped layout (profiles/r01_other_configs.txt)
-        e->ilv = realsize == 4 && e->N >= 512 && e->B <= 96 && !(mv && atoi(mv) != 0);
+        e->ilv = realsize == 4 && e->N >= 512 && !(mv && atoi(mv) != 0);
     }
     {   // BFIR_PAIR=0 (tuning aid) keeps the planar staging kernels
         const char *pv = getenv("BFIR_PAIR");

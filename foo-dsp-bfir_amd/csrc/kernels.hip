@@ -493,7 +493,19 @@ __device__ __forceinline__ void cmac4(v4f &ar, v4f &ai, const v4f &xr, const v4f
     ai.hi = __builtin_elementwise_fma(xr.hi, hi.hi, ai.hi); ai.hi = __builtin_elementwise_fma(xi.hi, hr.hi, ai.hi);
 }
 
-template <int D, bool DCNY>
+// (re, im) pair layout: a group is A = (r0 i0 r1 i1), B = (r2 i2 r3 i3); the same four fused
+// multiply-adds per bin as cmac4, on the components where they lie (no shuffle, same rounding)
+__device__ __forceinline__ void cmac4_pairs(v4f &aA, v4f &aB, const v4f &xA, const v4f &xB, const v4f &hA, const v4f &hB)
+{
+    aA.x = fmaf(xA.x, hA.x, aA.x); aA.x = fmaf(xA.y, -hA.y, aA.x); aA.y = fmaf(xA.x, hA.y, aA.y); aA.y = fmaf(xA.y, hA.x, aA.y);
+    aA.z = fmaf(xA.z, hA.z, aA.z); aA.z = fmaf(xA.w, -hA.w, aA.z); aA.w = fmaf(xA.z, hA.w, aA.w); aA.w = fmaf(xA.w, hA.z, aA.w);
+    aB.x = fmaf(xB.x, hB.x, aB.x); aB.x = fmaf(xB.y, -hB.y, aB.x); aB.y = fmaf(xB.x, hB.y, aB.y); aB.y = fmaf(xB.y, hB.x, aB.y);
+    aB.z = fmaf(xB.z, hB.z, aB.z); aB.z = fmaf(xB.w, -hB.w, aB.z); aB.w = fmaf(xB.z, hB.w, aB.w); aB.w = fmaf(xB.w, hB.z, aB.w);
+}
+
+// PAIRS: the spectra are (re, im) pairs (MacArgs.interleaved); "planes" 0 / 1 of a group are then its
+// first / second 16 bytes (bins 0-1 / bins 2-3) instead of the real / imaginary parts.
+template <int D, bool DCNY, bool PAIRS>
 __device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], float (&dc)[8], float (&ny)[8],
                                               v4f (&wr)[8], v4f (&wi)[8], v4f (*s_ring)[2][64],
                                               v4f (*s_h)[2][64], const v4f *__restrict__ duty_base,
@@ -537,10 +549,18 @@ __device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], fl
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int idx = (j - ii + 8) % 8;            // window slot holding X[t0 + j - i]
-                    cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi, nhi);
-                    if constexpr (DCNY) {
-                        dc[j] = fma(wr[idx].x, hr.x, dc[j]);
-                        ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                    if constexpr (PAIRS) {
+                        cmac4_pairs(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                        if constexpr (DCNY) {              // bin 0 = (DC, Nyquist): .x and .y of the first half
+                            dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                            ny[j] = fma(wr[idx].y, hr.y, ny[j]);
+                        }
+                    } else {
+                        cmac4(accr[j], acci[j], wr[idx], wi[idx], hr, hi, nhi);
+                        if constexpr (DCNY) {
+                            dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                            ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                        }
                     }
                 }
                 // publish the operands of step i+1, refill the queue slot with those of step i+1+D
@@ -556,7 +576,7 @@ __device__ __forceinline__ void mac_lds_steps(v4f (&accr)[8], v4f (&acci)[8], fl
 #undef BFIR_DUTY_STORE
 }
 
-template <int D>
+template <int D, bool PAIRS>
 __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
 {
     __shared__ __attribute__((aligned(16))) v4f s_ring[32][2][64];
@@ -589,17 +609,20 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
     const bool duty_is_h = wv < 2;
     const int plane = wv & 1;
     if (bt == 0)
-        mac_lds_steps<D, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
+        mac_lds_steps<D, true, PAIRS>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
                                nb, ring, sl_tb, lane, wv);
     else
-        mac_lds_steps<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
+        mac_lds_steps<D, false, PAIRS>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane,
                                 nb, ring, sl_tb, lane, wv);
     float *__restrict__ Y = (float *)a.y + (long)gc * a.y_ch_stride;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int t = t0 + j;
         if (t < a.n_t) {
-            if (g == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            if (g == 0) {
+                if constexpr (PAIRS) { accr[j].x = dc[j]; accr[j].y = ny[j]; }
+                else { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            }
             v4f *yo = (v4f *)(Y + (long)t * a.N) + 2 * g;
             yo[0] = accr[j]; yo[1] = acci[j];
         }
@@ -815,11 +838,11 @@ template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStre
                            p0);
 }
 
-template <int D> static void launch_mac_lds(const MacArgs &a, hipStream_t s)
+template <int D, bool PAIRS = false> static void launch_mac_lds(const MacArgs &a, hipStream_t s)
 {
     const int nbt = a.N / 8 / 64;              // bin tiles of 64 groups
     const int nTQ = (a.n_t + 31) / 32;         // time tiles of 32 blocks
-    hipLaunchKernelGGL((k_mac_lds<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+    hipLaunchKernelGGL((k_mac_lds<D, PAIRS>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
 }
 
 template <typename T, int TT, int WPE, int D> static void launch_mac_t(const MacArgs &a, hipStream_t s)
@@ -853,6 +876,13 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         const int v = mac_variant();
         // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns
         const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
+        static const bool batched_only = getenv("BFIR_MAC_BATCHED") != nullptr;   // tuning aid
+        if (a.interleaved && a.B > 32 && tt >= 32 && !batched_only) {
+            // more partitions than one register batch: the LDS-shared kernel on the pair layout beats
+            // re-reading X and Y once per batch of 32 (profiles/r01_other_configs.txt)
+            launch_mac_lds<8, true>(a, s);
+            return;
+        }
         if (a.interleaved) {                          // the engine picked the pair layout (fp32, N >= 512)
             if (pb == 4) launch_mac_stream<4, 4>(a, s);
             else if (pb == 8) launch_mac_stream<8, 8>(a, s);

@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
@@ -38,8 +38,13 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append(cmd)
         objs.append(o)
+    if jobs:   # the translation units are independent: compile them side by side (4 at most)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            for r in pool.map(lambda c: subprocess.run(c, check=True), jobs):
+                pass
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
         if verbose:

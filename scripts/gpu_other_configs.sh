@@ -14,8 +14,8 @@ print("%-6s %-34s %9.1f Msamples/s  %8.3f ms/step  blocks/step %d  blocks/launch
     d["config"]["blocks_per_launch"], d["config"]["streams_total"], r["kernel_ms_share"]))
 PY
 }
-run cfg2 --workload cfg2_2ch_65536tap_L8192_fp32 --blocks 4096 --chunk 1024
-run cfg4 --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64 --chunk 64
-run cfg5 --workload cfg5_2ch_262144tap_L4096_fp64 --blocks 2048 --chunk 512
+run cfg2 --workload cfg2_2ch_65536tap_L8192_fp32 --blocks 8192 --chunk 0
+run cfg4 --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64 --chunk 0
+run cfg5 --workload cfg5_2ch_262144tap_L4096_fp64 --blocks 8192 --chunk 0
 run cfg3g --workload cfg3_8ch_131072tap_L4096_fp32        # headline again, for the same box
 BFIR_PAIR=0 run cfg3_general_path --workload cfg3_8ch_131072tap_L4096_fp32

@@ -630,6 +630,132 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds(MacArgs a, int nbt, int nTQ)
 }
 
 // ---------------------------------------------------------------------------
+// k_mac_lds_d: the LDS-shared MAC for fp64 (grouped layout)
+// ---------------------------------------------------------------------------
+// k_mac<double> has room for one wave per SIMD only (4 output blocks x 4 bins of accumulators and
+// window are 128 registers before anything else) and fetches every operand from L2 itself.  This
+// is k_mac_lds with half the time tile: 4 waves x 4 blocks = 16 blocks per workgroup, a 16-entry
+// ring of 32-byte lanes (64 KiB) + the double-buffered H planes (8 KiB): two workgroups and two
+// waves per SIMD per CU, one 32-byte duty load per lane and step.  Same fma chain as k_mac.
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cmac4d(v4d &ar, v4d &ai, const v4d &xr, const v4d &xi, const v4d &hr, const v4d &hi)
+{
+    ar = __builtin_elementwise_fma(xr, hr, ar); ar = __builtin_elementwise_fma(-xi, hi, ar);
+    ai = __builtin_elementwise_fma(xr, hi, ai); ai = __builtin_elementwise_fma(xi, hr, ai);
+}
+
+template <int D, bool DCNY>
+__device__ __forceinline__ void mac_lds_steps_d(v4d (&accr)[4], v4d (&acci)[4], double (&dc)[4], double (&ny)[4],
+                                                v4d (&wr)[4], v4d (&wi)[4], v4d (*s_ring)[2][64], v4d (*s_h)[2][64],
+                                                const v4d *__restrict__ dbase, long duty_slot4, bool duty_is_h,
+                                                int duty_plane, int nb, int ring, int sl_tb, int lane, int wv)
+{
+    v4d q[D];
+    int dnext = duty_is_h ? 0 : sl_tb;
+#define BFIR_DUTY_ADVANCE()                                                                         \
+    do {                                                                                            \
+        if (duty_is_h) { if (dnext < nb - 1) dnext += 1; }                                          \
+        else { dnext -= 1; if (dnext < 0) dnext += ring; }                                          \
+    } while (0)
+#define BFIR_DUTY_LOAD() dbase[dnext * duty_slot4 + duty_plane]
+#define BFIR_DUTY_STORE(s_, v_)                                                                     \
+    do {                                                                                            \
+        v4d *dst_ = duty_is_h ? &s_h[(s_) & 1][duty_plane][lane] : &s_ring[(-(s_)) & 15][duty_plane][lane]; \
+        *dst_ = (v_);                                                                               \
+    } while (0)
+    if (duty_is_h) { const v4d h0 = BFIR_DUTY_LOAD(); BFIR_DUTY_STORE(0, h0); }
+#pragma unroll
+    for (int d = 0; d < D; d++) { BFIR_DUTY_ADVANCE(); q[(1 + d) % D] = BFIR_DUTY_LOAD(); }   // steps 1 .. D
+    __syncthreads();
+    for (int i0 = 0; i0 < nb; i0 += 4) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = i0 + ii;
+            if (i < nb) {   // uniform over the workgroup
+                const v4d hr = s_h[ii & 1][0][lane], hi = s_h[ii & 1][1][lane];
+                if (i > 0) {
+                    const int e = (4 * wv - i) & 15;             // ring entry holding X[tb + 4 wv - i]
+                    wr[(4 - ii) % 4] = s_ring[e][0][lane]; wi[(4 - ii) % 4] = s_ring[e][1][lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int idx = (j - ii + 4) % 4;            // window slot holding X[t0 + j - i]
+                    cmac4d(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                    if constexpr (DCNY) {
+                        dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                        ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                    }
+                }
+                BFIR_DUTY_STORE(i + 1, q[(ii + 1) % D]);
+                BFIR_DUTY_ADVANCE();
+                q[(ii + 1) % D] = BFIR_DUTY_LOAD();
+                __syncthreads();
+            }
+        }
+    }
+#undef BFIR_DUTY_ADVANCE
+#undef BFIR_DUTY_LOAD
+#undef BFIR_DUTY_STORE
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_mac_lds_d(MacArgs a, int nbt, int nTQ)
+{
+    __shared__ __attribute__((aligned(32))) v4d s_ring[16][2][64];
+    __shared__ __attribute__((aligned(32))) v4d s_h[2][2][64];
+    static_assert(4 % D == 0, "prefetch depth must divide the unroll");
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTQ, tq = w - s * nTQ;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = bt * 64 + lane;
+    const int tb = tq * 16, t0 = tb + 4 * wv;
+    const long slot4 = a.N / 4;
+    const v4d *__restrict__ X = (const v4d *)((const double *)a.x + (long)gc * a.x_ch_stride) + 2 * g;
+    const v4d *__restrict__ H = (const v4d *)((const double *)a.h + (long)gc * a.h_ch_stride) + 2 * g;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+    const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
+    v4d accr[4], acci[4], wr[4], wi[4];
+    double dc[4], ny[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        accr[j] = v4d{0, 0, 0, 0}; acci[j] = v4d{0, 0, 0, 0};
+        dc[j] = 0.0; ny[j] = 0.0;
+        int sj = sl_tb + 4 * wv + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot4]; wi[j] = X[sj * slot4 + 1];
+        s_ring[4 * wv + j][0][lane] = wr[j]; s_ring[4 * wv + j][1][lane] = wi[j];
+    }
+    const bool duty_is_h = wv < 2;
+    const int plane = wv & 1;
+    if (bt == 0)
+        mac_lds_steps_d<D, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane, nb,
+                                 ring, sl_tb, lane, wv);
+    else
+        mac_lds_steps_d<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, duty_is_h ? H : X, slot4, duty_is_h, plane, nb,
+                                  ring, sl_tb, lane, wv);
+    double *__restrict__ Y = (double *)a.y + (long)gc * a.y_ch_stride;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) {
+            if (g == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            v4d *yo = (v4d *)(Y + (long)t * a.N) + 2 * g;
+            yo[0] = accr[j]; yo[1] = acci[j];
+        }
+    }
+}
+
+template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
+{
+    const int nbt = a.N / 8 / 64;              // bin tiles of 64 groups
+    const int nTQ = (a.n_t + 15) / 16;         // time tiles of 16 blocks
+    hipLaunchKernelGGL((k_mac_lds_d<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+}
+
+// ---------------------------------------------------------------------------
 // k_mac_stream: the time-streaming form of the same sums (fp32; B > PB in batches of PB partitions)
 // ---------------------------------------------------------------------------
 // One lane owns ONE bin of one channel for a range of output blocks and keeps
@@ -901,7 +1027,11 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         else if (tt >= 2) launch_mac_t<float, 2, 4, 1>(a, s);
         else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
-        if (tt >= 4) launch_mac_t<double, 4, 1, 1>(a, s);   // 1 wave/SIMD: the 2-wave build spills to scratch
+        static const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid
+        if (a.N >= 512 && tt >= 16 && v64 == 0) launch_mac_lds_d<2>(a, s);
+        else if (a.N >= 512 && tt >= 16 && v64 == 2) launch_mac_lds_d<4>(a, s);
+        else if (a.N >= 512 && tt >= 16 && v64 == 3) launch_mac_lds_d<1>(a, s);
+        else if (tt >= 4) launch_mac_t<double, 4, 1, 1>(a, s);   // 1 wave/SIMD: the 2-wave build spills to scratch
         else if (tt >= 2) launch_mac_t<double, 2, 3, 1>(a, s);
         else launch_mac_t<double, 1, 4, 1>(a, s);
     }

@@ -135,3 +135,21 @@ def test_more_partitions_than_one_register_batch(orc, bfir, L, B, C, nb, chunk):
     for e in (a, b):
         e.set_chunk(chunk); e.set_coeff(h)
     assert np.array_equal(a.run(x)[1], b.run(x)[1])
+
+
+def test_automatic_chunk_equals_explicit_chunks(orc, bfir):
+    """set_chunk(0) (the default) picks the launch size itself; results do not depend on it."""
+    L, B, C, nb = 512, 3, 2, 70
+    h, x = _data(orc, C, 1300, nb * L, seed=3)
+    outs = []
+    for chunk in (0, 7, 64):
+        eng = bfir.Brutefir(L, B, 4, C)
+        assert eng.set_chunk(chunk) in (0, None)
+        eng.set_coeff(h)
+        rc, y = eng.run(x)
+        assert rc == 0
+        outs.append(y)
+        eng.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h)
+    assert rel_err(outs[0], ref.run(x)[1]) <= TOL[4]

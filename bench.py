@@ -74,6 +74,23 @@ def measured_traffic(kernel, workload, chunk):
     return None
 
 
+def measured_stream_peaks():
+    """Best read / write / copy GB/s of scripts/ubench/hbm_stream.hip on this GPU model
+    (profiles/r01_hbm_stream.txt; SURVEY 8(d) asks for the measured stream peak next to the 8 TB/s spec)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_hbm_stream.txt")
+    best = {}
+    try:
+        for line in open(path):
+            for key in ("read", "write", "copy"):
+                m = re.search(key + r" (\d+) GB/s", line)
+                if m:
+                    best[key + "_GBs"] = max(best.get(key + "_GBs", 0), int(m.group(1)))
+    except OSError:
+        return None
+    return best or None
+
+
 def cpu_baseline(O, C, taps, L, B, s, h, x, budget_s=12.0):
     """Time the oracle (1 thread) on a bounded sample: B warm-up blocks, then blocks until ~budget."""
     eng = O.Engine(L, B, s, C)
@@ -89,9 +106,43 @@ def cpu_baseline(O, C, taps, L, B, s, h, x, budget_s=12.0):
         dt += time.perf_counter() - t0
         n += nb_avail
         assert rc == 0
-    return {"value": n * L * C / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d blocks (%d channel-samples) after %d warm-up blocks, oracle/bfir_oracle.c, "
-                      "1 thread, %.1f s" % (n, n * L * C, warm, dt)}
+    out = {"value": n * L * C / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "%d blocks (%d channel-samples) after %d warm-up blocks, oracle/bfir_oracle.c, "
+                     "1 thread, %.1f s" % (n, n * L * C, warm, dt)}
+    # also all host cores, channel-parallel (one single-channel engine per thread; the
+    # reference itself is single-threaded per instance).  ctypes releases the GIL inside the oracle.
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, min(C, len(os.sched_getaffinity(0))))
+        engs, cols = [], []
+        for c in range(C):
+            e1 = O.Engine(L, B, s, 1)
+            assert e1.set_coeff([h[c]]) == 0
+            engs.append(e1)
+            cols.append(np.ascontiguousarray(x[:nb_avail * L, c:c + 1]))
+        nb_par = nb_avail
+        def one(i):
+            engs[i].run(cols[i][:warm * L])
+            return engs[i].run(cols[i][:nb_par * L])[0]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            rcs = list(pool.map(one, range(C)))
+        dtp = time.perf_counter() - t0
+        assert all(r == 0 for r in rcs)
+        model = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip(); break
+        except OSError:
+            pass
+        out["all_cores"] = {"value": (nb_par + warm) * L * C / dtp / 1e6, "unit": "Msamples/s", "cores": threads,
+                            "cpu_model": model, "host_cores_available": len(os.sched_getaffinity(0)),
+                            "sample": "%d blocks per channel, %d single-channel engines on %d threads, %.1f s"
+                                      % (nb_par + warm, C, threads, dtp)}
+    except Exception as exc:   # the extra row must never cost the bench line
+        out["all_cores"] = {"error": repr(exc)}
+    return out
 
 
 def main():
@@ -263,6 +314,7 @@ def main():
                               "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": measured_traffic(kname, args.workload, args.chunk)}
             roofline["kernels"] = per
+            roofline["peak_measured"] = measured_stream_peaks()
             # The timed region runs fwd(k+1), mac(k) and inv(k-1) concurrently on three streams, so
             # the launch durations above are those of kernels SHARING the GPU.  One extra untimed pass
             # on a serial schedule (BFIR_PIPE=1) gives each kernel's duration with the GPU to itself.

@@ -4,23 +4,39 @@
 Workload (BASELINE.json configs[2], the headline): 8 channels, 131072-tap IR,
 4096-sample partitions (N = 8192, B = 32), fp32, synthetic uniform noise.
 One STEP = one bfir_engine_run_device call over `--blocks` consecutive blocks
-of input that is already resident in HBM.  Metric: output channel-samples/s.
+of input that is already resident in HBM (generated there).  Metric: output
+channel-samples/s.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank runs its
-own independent 8-channel engine (weak scaling, no data-path collective).
+
+N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this
+process is one rank; started plainly with --gpus N it spawns the N ranks itself
+(fresh child processes, before anything touches a GPU) and relays rank 0's line.
+  --shard replicas  (default) every rank runs its own independent 8-channel
+                    stream: weak scaling, the units are streams
+  --shard channels  ONE 8-channel stream, rank r owns channels r*C/N .. : strong
+                    scaling (channels never mix, brutefir/brutefir.cpp:252-334)
+  --streams S       S independent engines dealt out to the ranks (configs[3])
+No rank ever exchanges audio with another; the only communication is the MAX /
+SUM reduction of the timing.
 
 The JSON line also carries
-  roofline     algorithmic HBM bytes of the dominant kernel / its mean launch
-               time (HIP events on the launch stream) against 8 TB/s; the timed
-               region overlaps three kernels, so the same figure from an untimed
-               serial-schedule pass is given beside it (*_exclusive)
-  cpu_baseline the CPU oracle (a port of the reference algorithm) timed on a
-               bounded sample of the same workload on this host, 1 thread.
+  roofline      per kernel: algorithmic HBM bytes / mean launch time (HIP events
+                on the launch stream, inside the timed region) against 8 TB/s, the
+                same from an untimed serial-schedule pass (*_exclusive), the
+                PMC-measured traffic when profiles/traffic_*.json matches this
+                very csrc/ (sha stamped), and the pipeline-level traffic / time
+  cpu_baseline  the CPU oracle (a port of the reference algorithm) on a bounded
+                sample of the same workload on this host: 1 thread and all cores
+  parity_rel_err_vs_oracle   sampled blocks of the TIMED output buffer
+  end_to_end    the host-pointer entry (bfir_engine_run, PCIe inclusive)
+  latency_one_block_us       one run() per block, the plug-in's call pattern
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,11 +54,23 @@ WORKLOADS = {
     "cfg2_2ch_65536tap_L8192_fp32": (2, 65536, 8192, 4),
     "cfg5_2ch_262144tap_L4096_fp64": (2, 262144, 4096, 8),
     "cfg4_stereo_65536tap_L4096_fp32": (2, 65536, 4096, 4),   # per stream; use with --streams
-    # not a BASELINE config: the plug-in's own partition size (FILTER_LEN 1024), B = 128 partitions
+    # not BASELINE configs: the plug-in's own partition size (FILTER_LEN 1024)
     "plugin_8ch_131072tap_L1024_fp32": (8, 131072, 1024, 4),
     "plugin_8ch_65536tap_L1024_fp32": (8, 65536, 1024, 4),
     "plugin_8ch_98304tap_L1024_fp32": (8, 98304, 1024, 4),
+    "plugin_2ch_65536tap_L1024_fp64": (2, 65536, 1024, 8),    # the shipped REALSIZE 8 (common.h:17-19)
+    "plugin_2ch_65536tap_L1024_fp32": (2, 65536, 1024, 4),
 }
+
+
+def csrc_sha():
+    """Identity of the kernels a PMC traffic file belongs to: sha256 over csrc/ sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "foo-dsp-bfir_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes_per_block(C, B, N, L, s, fused_io=False):
@@ -58,20 +86,22 @@ def algorithmic_bytes_per_block(C, B, N, L, s, fused_io=False):
     }
 
 
-def measured_traffic(kernel, workload, chunk):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_*.json,
-    written by scripts/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command), or None when no pass matches this workload and blocks-per-launch."""
+def measured_traffic_table(workload, chunk):
+    """Per-kernel HBM bytes per launch from a committed PMC pass (profiles/traffic_*.json, written by
+    scripts/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command).
+    A file is used only when it was taken on THIS csrc/ (meta.csrc_sha), this workload and this
+    blocks-per-launch; anything else would be a stale number, so it yields None."""
     import glob
+    sha = csrc_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         m = d.get("meta", {})
-        if m.get("workload") == workload and int(m.get("chunk", -1)) == int(chunk) and kernel in d["per_launch"]:
-            return d["per_launch"][kernel]["total_bytes"]
-    return None
+        if m.get("workload") == workload and int(m.get("chunk", -1)) == int(chunk) and m.get("csrc_sha") == sha:
+            return {k: v["total_bytes"] for k, v in d["per_launch"].items()}, os.path.basename(path)
+    return None, None
 
 
 def measured_stream_peaks():
@@ -91,74 +121,127 @@ def measured_stream_peaks():
     return best or None
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
 def cpu_baseline(O, C, taps, L, B, s, h, x, budget_s=12.0):
     """Time the oracle (1 thread) on a bounded sample: B warm-up blocks, then blocks until ~budget."""
     eng = O.Engine(L, B, s, C)
     assert eng.set_coeff(h) == 0
-    nb_avail = min(x.shape[0] // L, 8192)      # one timed pass stays near the budget
+    nb_avail = x.shape[0] // L
     warm = min(B, nb_avail)
     eng.run(x[:warm * L])
-    # timed: whole passes over the resident input (the stream simply continues), ~budget_s
     n, dt = 0, 0.0
-    while dt < budget_s:
+    while dt < budget_s:       # whole passes over the sample (the stream simply continues)
         t0 = time.perf_counter()
         rc, _ = eng.run(x[:nb_avail * L])
         dt += time.perf_counter() - t0
         n += nb_avail
         assert rc == 0
-    out = {"value": n * L * C / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+    fft = O.fft_backend() if hasattr(O, "fft_backend") else "own CPU FFT (FFTW unavailable)"
+    out = {"value": n * L * C / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port", "fft": fft,
+           "cpu_model": cpu_model(),
            "sample": "%d blocks (%d channel-samples) after %d warm-up blocks, oracle/bfir_oracle.c, "
                      "1 thread, %.1f s" % (n, n * L * C, warm, dt)}
-    # SURVEY 8(d): also all host cores, channel-parallel (one single-channel engine per thread; the
-    # reference itself is single-threaded per instance).  ctypes releases the GIL inside the oracle.
+    # SURVEY 8(d): also all host cores.  The reference is single-threaded per instance, so the
+    # all-cores arrangement is replicated engines: one single-channel engine per thread, thread i
+    # on channel i mod C of the same sample.  ctypes releases the GIL inside the oracle.
     try:
         from concurrent.futures import ThreadPoolExecutor
-        threads = max(1, min(C, len(os.sched_getaffinity(0))))
+        avail = len(os.sched_getaffinity(0))
+        threads = max(1, min(avail, int(os.environ.get("BFIR_CPU_THREADS", "64"))))
+        nb_par = min(nb_avail, 2048)
         engs, cols = [], []
-        for c in range(C):
+        for i in range(threads):
             e1 = O.Engine(L, B, s, 1)
-            assert e1.set_coeff([h[c]]) == 0
+            assert e1.set_coeff([h[i % C]]) == 0
             engs.append(e1)
-            cols.append(np.ascontiguousarray(x[:nb_avail * L, c:c + 1]))
-        nb_par = nb_avail
+            cols.append(np.ascontiguousarray(x[:nb_par * L, (i % C):(i % C) + 1]))
+
         def one(i):
             engs[i].run(cols[i][:warm * L])
             return engs[i].run(cols[i][:nb_par * L])[0]
         t0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=threads) as pool:
-            rcs = list(pool.map(one, range(C)))
+            rcs = list(pool.map(one, range(threads)))
         dtp = time.perf_counter() - t0
         assert all(r == 0 for r in rcs)
-        model = ""
-        try:
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip(); break
-        except OSError:
-            pass
-        out["all_cores"] = {"value": (nb_par + warm) * L * C / dtp / 1e6, "unit": "Msamples/s", "cores": threads,
-                            "cpu_model": model, "host_cores_available": len(os.sched_getaffinity(0)),
-                            "sample": "%d blocks per channel, %d single-channel engines on %d threads, %.1f s"
-                                      % (nb_par + warm, C, threads, dtp)}
+        out["all_cores"] = {"value": threads * (nb_par + warm) * L / dtp / 1e6, "unit": "Msamples/s",
+                            "cores": threads, "host_cores_available": avail,
+                            "sample": "%d single-channel engines (channel i mod %d) on %d threads, %d blocks "
+                                      "each, %.1f s" % (threads, C, threads, nb_par + warm, dtp)}
     except Exception as exc:   # the extra row must never cost the bench line
         out["all_cores"] = {"error": repr(exc)}
     return out
 
 
-def main():
+# ---------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks ourselves
+# ---------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay
+    rank 0's stdout, return the worst exit code.  The parent never initialises a GPU and never re-execs."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def spawn_check(args):
+    """CPU rehearsal of the launcher plumbing (tests/test_bench_spawn.py): rendezvous over gloo, the two
+    timing reductions, one JSON line from rank 0.  No GPU, no engine, not a measurement."""
+    import torch.distributed as dist
+    from foo_dsp_bfir_amd import sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    worst = sharding.max_over_ranks(1.0 + rank)
+    total = sharding.sum_over_ranks(10.0)
+    lo, hi = sharding.shard_range(8, rank, world)
+    chans = sharding.sum_over_ranks(hi - lo)
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "max_elapsed": worst, "sum_units": total,
+                          "channels_covered": chans}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=16384,
-                    help="blocks per step (one run_device call; the chunk pipeline drains at call boundaries)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "4096")),
-                    help="blocks per kernel launch")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="blocks per step (one run_device call; the chunk pipeline drains at call boundaries); "
+                         "0 = sized so that 20 steps time at least a second (headline: 163840 = 40 launches)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BFIR_CHUNK", "0")),
+                    help="blocks per kernel launch (0 = the engine's automatic choice: 4096, fewer for many channels)")
     ap.add_argument("--workload", default="cfg3_8ch_131072tap_L4096_fp32", choices=sorted(WORKLOADS))
+    ap.add_argument("--shard", default="replicas", choices=["replicas", "channels"],
+                    help="N > 1: replicas = one independent stream per rank (weak scaling); channels = one "
+                         "stream, its channels dealt out to the ranks (strong scaling)")
     ap.add_argument("--streams", type=int, default=0,
                     help="total independent engines dealt out to the ranks (0 = one per rank); "
-                         "configs[3]: --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 64")
+                         "configs[3]: --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and latency_one_block_us")
     ap.add_argument("--no-exclusive-pass", action="store_true",
                     help="skip the untimed serial-schedule pass (rocprofv3 runs: keeps the kernel trace to the overlapped schedule)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -167,7 +250,45 @@ def main():
                     help="process-group backend for the timing reduction (nccl = RCCL; gloo lets several "
                          "ranks rehearse the N > 1 path on one GPU together with --device)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
-    args = ap.parse_args()
+    ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def auto_chunk(n_ch, N, B, s):
+    """The engine's automatic blocks-per-launch (csrc/engine.hip ensure_chunk): 4096, fewer when the
+    delay line of that many blocks would pass 4 GiB."""
+    slots = (4 << 30) // (n_ch * N * s)
+    return int(max(16, min(4096, (slots - B) // 2)))
+
+
+def default_blocks(n_eng, C, L, B, s, chunk):
+    """Blocks per step such that 20 steps time at least a second on one MI355X (round-1 speeds):
+    the resident job grows, the launch geometry (blocks per launch) does not.  At most 32 GiB per
+    I/O buffer and rank."""
+    gsps = (95.0 if s == 4 else 22.0) * (32.0 / B if B > 32 else 1.0)      # rough Gsamples/s, profiles/r01_*
+    want = 0.1 * gsps * 1e9 / (n_eng * C * L)                              # ~100 ms per step
+    cap = (32 << 30) // (n_eng * C * L * s)
+    nb = int(min(want, cap)) // chunk * chunk
+    return max(chunk, nb)
+
+
+def mac_range(tc, N, n_ch, B):
+    """Blocks per range of the streaming MAC for a launch of tc blocks (csrc/kernels.hip
+    launch_mac_stream); 0 when the LDS-shared kernel runs instead (B > 32)."""
+    if B > 32:
+        return 0
+    PB = 4 if B <= 4 else 8 if B <= 8 else 16 if B <= 16 else 32
+    want = max(1, 512 // max(1, (N // 2 // 256) * n_ch))
+    return max(1, -(-tc // (want * PB))) * PB
+
+
+def main():
+    args = parse_args()
+    argv = sys.argv[1:]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+    if args.spawn_check:
+        return spawn_check(args)
 
     import torch
     import torch.distributed as dist
@@ -186,49 +307,55 @@ def main():
     red_dev = dev if args.dist_backend == "nccl" else None      # gloo reduces CPU tensors
 
     import foo_dsp_bfir_amd as bfir   # raises if the HIP library is missing
-
     from foo_dsp_bfir_amd import sharding
 
-    C, taps, L, s = WORKLOADS[args.workload]
+    C_all, taps, L, s = WORKLOADS[args.workload]
     N, B = 2 * L, (taps + L - 1) // L
     rdt = np.float32 if s == 4 else np.float64
-    nb = args.blocks
-    # Units = independent engines (streams).  Headline: one 8-channel engine per GPU (weak
-    # scaling).  --streams S: S engines in total, dealt out to the ranks (strong scaling,
-    # BASELINE.json configs[3] with S = 256); no rank ever exchanges audio with another.
+    tdt = torch.float32 if s == 4 else torch.float64
+    # Units.  replicas: independent streams, one per rank (weak).  channels: the channels of ONE
+    # stream (strong).  --streams S: S engines dealt out to the ranks (strong, configs[3]).
+    ch_lo, ch_hi = 0, C_all
     if args.streams > 0:
         lo, hi = sharding.shard_range(args.streams, rank, world)
-        n_eng, first_stream, scaling = hi - lo, lo, "strong"
+        n_eng, first_stream, scaling, mode = hi - lo, lo, "strong", "streams dealt out to ranks"
+    elif args.shard == "channels" and world > 1:
+        ch_lo, ch_hi = sharding.shard_range(C_all, rank, world)
+        n_eng, first_stream, scaling, mode = (1 if ch_hi > ch_lo else 0), 0, "strong", "channels of one stream dealt out to ranks"
     else:
-        n_eng, first_stream, scaling = 1, rank, "weak"
+        n_eng, first_stream, scaling, mode = 1, rank, "weak", "one independent stream per rank"
+    C = ch_hi - ch_lo
+    chunk = args.chunk if args.chunk > 0 else auto_chunk(max(1, n_eng * C), N, B, s)
+    nb = args.blocks if args.blocks > 0 else default_blocks(max(1, n_eng), C_all, L, B, s, chunk)
+    chunk = min(chunk, nb)
 
-    # synthetic audio / IR of SURVEY.md 8(d); stream k is the same whichever rank owns it
-    n = np.arange(taps, dtype=np.float64)
-    hs, xs = [], []
+    # synthetic audio / IR of SURVEY.md 8(d): IR = uniform[-1,1) * exp(-6 n / taps), sum|h| = 1 (host,
+    # numpy default_rng(3 + 1000 k)); audio = uniform [-1,1) generated in HBM, one torch generator per
+    # (stream, channel) so a stream's channel is the same samples whichever rank owns it.
+    n_idx = np.arange(taps, dtype=np.float64)
+    hs = []
     for k in range(first_stream, first_stream + n_eng):
         rng = np.random.default_rng(3 + 1000 * k)
-        h = []
-        for _ in range(C):
-            v = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n / taps)
-            h.append((v / np.abs(v).sum()).astype(rdt))
-        hs.append(h)
-        if s == 4:   # generated in float32, in place: no float64 temporary of the whole job
-            xk = rng.random((nb * L, C), dtype=np.float32)
-            xk *= 2.0; xk -= 1.0
-        else:
-            xk = rng.uniform(-1.0, 1.0, (nb * L, C)).astype(rdt)
-        xs.append(xk)
-    h, x_host = (hs[0], xs[0]) if n_eng else (None, None)
+        h_all = []
+        for _ in range(C_all):
+            v = rng.uniform(-1.0, 1.0, taps) * np.exp(-6.0 * n_idx / taps)
+            h_all.append((v / np.abs(v).sum()).astype(rdt))
+        hs.append(h_all[ch_lo:ch_hi])
 
     eng = d_in = d_out = None
-    if n_eng:
+    if n_eng and C:
+        d_in = torch.empty((n_eng, nb * L, C), dtype=tdt, device=dev)
+        for k in range(n_eng):
+            for c in range(C):
+                g = torch.Generator(device=dev)
+                g.manual_seed(7 + 1000 * (first_stream + k) + (ch_lo + c))
+                d_in[k, :, c].uniform_(-1.0, 1.0, generator=g)
+        d_out = torch.empty_like(d_in)
         eng = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
-        eng.set_chunk(args.chunk)
+        eng.set_chunk(chunk)
         for k in range(n_eng):
             assert eng.set_coeff(hs[k], engine_index=k) == 0
-        d_in = torch.from_numpy(xs[0][None] if n_eng == 1 else np.stack(xs)).to(dev)       # [n_eng, nb*L, C]
-        d_out = torch.empty_like(d_in)
-    eng_stride = nb * L * C * (4 if s == 4 else 8)
+    eng_stride = nb * L * C * s
     stream = torch.cuda.current_stream()
 
     def step():
@@ -259,6 +386,40 @@ def main():
         prof = eng.profile()
         eng.set_profiling(False)
 
+    # parity of the TIMED output: sampled blocks of d_out as the last timed step left it.  Every step
+    # reads the same resident input and continues the previous step's history, so global block g of
+    # the stream is block g mod nb of the buffer; a block needs the B+1 input blocks ending at it.
+    parity = None
+    parity_note = None
+    if eng is not None and rank == 0 and not args.no_cpu_baseline and args.steps + args.warmup > 0:
+        from oracle import oracle as O   # checker + CPU baseline only
+        O.build()
+        total_steps = args.warmup + args.steps
+        g_base = (total_steps - 1) * nb
+        R = mac_range(chunk, N, n_eng * C, B) if s == 4 else 0
+        cand = {0, 1, nb // 2, nb - 2, nb - 1, chunk - 1, chunk % nb}
+        if R and R < nb:
+            cand |= {R - 1, R, nb - R - 1, nb - R}
+        cand = sorted(t for t in cand if 0 <= t < nb)
+
+        def in_block(k, g):
+            if g < 0:
+                return np.zeros((L, C), rdt)
+            t = g % nb
+            return d_in[k, t * L:(t + 1) * L].cpu().numpy()
+        worst = 0.0
+        for k in sorted({0, n_eng - 1}):
+            ref = O.sampled_reference(hs[k], lambda g: in_block(k, g), [g_base + t for t in cand], L, B, s, C)
+            for t in cand:
+                y = d_out[k, t * L:(t + 1) * L].cpu().numpy().astype(np.float64)
+                r = ref[g_base + t].astype(np.float64)
+                worst = max(worst, float(np.abs(y - r).max() / np.abs(r).max()))
+        parity = worst
+        parity_note = ("%d sampled blocks of the timed output buffer (last step; first/last block, launch and "
+                       "MAC-range boundaries, middle) of %d engine(s), each vs the oracle fed the B+1 input "
+                       "blocks ending at it" % (len(cand), len({0, n_eng - 1})))
+        assert parity <= (1e-5 if s == 4 else 1e-12), parity
+
     # untimed extra pass for the roofline object: the same engine configuration on a serial schedule
     exclusive = None
     if eng is not None and rank == 0 and not args.no_kernel_events and not args.no_exclusive_pass:
@@ -267,15 +428,16 @@ def main():
             ser = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
         finally:
             del os.environ["BFIR_PIPE"]
-        ser.set_chunk(args.chunk)
+        ser.set_chunk(chunk)
         for k in range(n_eng):
             assert ser.set_coeff(hs[k], engine_index=k) == 0
-        ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=eng_stride,
+        nbx = min(nb, 4 * chunk)
+        ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nbx, in_stride_bytes=eng_stride,
                        out_stride_bytes=eng_stride, stream=stream.cuda_stream)
         assert ser.sync() == 0
         ser.set_profiling(True)
-        for _ in range(2):
-            ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=eng_stride,
+        for _ in range(3):
+            ser.run_device(d_in.data_ptr(), d_out.data_ptr(), nbx, in_stride_bytes=eng_stride,
                            out_stride_bytes=eng_stride, stream=stream.cuda_stream)
         assert ser.sync() == 0
         exclusive = ser.profile()
@@ -292,18 +454,22 @@ def main():
         alg = algorithmic_bytes_per_block(C, B, N, L, s, fused_io)
         roofline = None
         if not args.no_kernel_events and any(v[1] for v in prof.values()):
+            traffic, traffic_file = measured_traffic_table(args.workload, chunk)
             dom = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[dom]
             blocks_per_launch = n_eng * args.steps * nb / launches   # engine-blocks in one launch
             achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": measured_traffic(dom, args.workload, args.chunk),
+                        "traffic": traffic.get(dom) if traffic else None,
+                        "frac_is": "this kernel's share of SURVEY 8(d)'s algorithmic bytes (see DESIGN 6) over its own "
+                                   "mean launch time while sharing the GPU with the other two kernels; "
+                                   "pipeline.* is the whole path",
+                        "traffic_source": traffic_file or "none matching this csrc/ (stale files are refused)",
                         "algorithmic_bytes_per_launch": int(alg[dom] * blocks_per_launch),
                         "avg_launch_ms": round(ms / launches, 5),
                         "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)
                                             for k, v in prof.items()}}
-            # the same figures for every kernel of the path (the dominant one is repeated above)
             per = {}
             for kname, (kms, kl) in prof.items():
                 if not kl:
@@ -312,9 +478,25 @@ def main():
                 ach = alg[kname] * bpl / (kms / kl * 1e-3) / 1e9
                 per[kname] = {"avg_launch_ms": round(kms / kl, 5), "algorithmic_bytes_per_launch": int(alg[kname] * bpl),
                               "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                              "traffic": measured_traffic(kname, args.workload, args.chunk)}
+                              "traffic": traffic.get(kname) if traffic else None}
             roofline["kernels"] = per
             roofline["peak_measured"] = measured_stream_peaks()
+            # whole path: one launch set (fwd + mac + inv of one chunk) per elapsed/launches of wall time
+            ms_set = elapsed * 1e3 / max(launches, 1)
+            alg_set = sum(alg.values()) * blocks_per_launch
+            compulsory = (2 * C * s * L) * blocks_per_launch          # input once in, output once out
+            pipe = {"ms_per_launch_set": round(ms_set, 5),
+                    "algorithmic_GBs": round(alg_set / (ms_set * 1e-3) / 1e9, 1),
+                    "algorithmic_frac_of_peak": round(alg_set / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "compulsory_bytes_per_launch_set": int(compulsory),
+                    "compulsory_GBs": round(compulsory / (ms_set * 1e-3) / 1e9, 1)}
+            if traffic:
+                tset = sum(traffic.get(k, 0) for k in per)
+                pipe.update({"traffic_bytes_per_launch_set": int(tset),
+                             "traffic_GBs": round(tset / (ms_set * 1e-3) / 1e9, 1),
+                             "traffic_frac_of_peak": round(tset / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic_over_compulsory": round(tset / compulsory, 3)})
+            roofline["pipeline"] = pipe
             # The timed region runs fwd(k+1), mac(k) and inv(k-1) concurrently on three streams, so
             # the launch durations above are those of kernels SHARING the GPU.  One extra untimed pass
             # on a serial schedule (BFIR_PIPE=1) gives each kernel's duration with the GPU to itself.
@@ -325,9 +507,8 @@ def main():
                     a_ex = alg[dom] * blocks_per_launch / (ex[dom] * 1e-3) / 1e9
                     roofline["achieved_exclusive"] = round(a_ex, 1)
                     roofline["frac_exclusive"] = round(a_ex / HBM_PEAK_GBS, 4)
-                    t = roofline["traffic"]
-                    if t:
-                        roofline["traffic_rate_exclusive_GBs"] = round(t / (ex[dom] * 1e-3) / 1e9, 1)
+                    if roofline["traffic"]:
+                        roofline["traffic_rate_exclusive_GBs"] = round(roofline["traffic"] / (ex[dom] * 1e-3) / 1e9, 1)
                 for kname, v in per.items():
                     if kname in ex:
                         v["exclusive_launch_ms"] = round(ex[kname], 5)
@@ -336,19 +517,14 @@ def main():
                         if v["traffic"]:
                             v["traffic_rate_exclusive_GBs"] = round(v["traffic"] / (ex[kname] * 1e-3) / 1e9, 1)
         cpu = None
-        parity = None
-        if not args.no_cpu_baseline:
-            from oracle import oracle as O   # checker + CPU baseline only
-            O.build()
-            cpu = cpu_baseline(O, C, taps, L, B, s, h, x_host)
-            # parity of this very workload: first blocks of a fresh GPU engine vs the oracle
-            k = min(nb, B + 3)
-            ref = O.Engine(L, B, s, C); ref.set_coeff(h)
-            _, y_ref = ref.run(x_host[:k * L])
-            chk = bfir.Brutefir(L, B, s, C, device=local); chk.set_coeff(h)
-            rc, y = chk.run(x_host[:k * L])
-            parity = float(np.abs(y.astype(np.float64) - y_ref).max() / np.abs(y_ref).max())
-            assert rc == 0 and parity <= (1e-5 if s == 4 else 1e-12), parity
+        extras = {}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as O
+            nb_cpu = min(nb, 4096)
+            x_cpu = d_in[0, :nb_cpu * L].cpu().numpy()
+            cpu = cpu_baseline(O, C, taps, L, B, s, hs[0], x_cpu)
+        if not args.no_extras and world == 1 and eng is not None:
+            extras = host_path_figures(bfir, torch, L, B, s, C, hs[0], d_in, local)
         result = {
             "metric": "Msamples/s (output channel-samples), 8ch 131072-tap FIR @4096-sample partitions"
                       if args.workload.startswith("cfg3") else "Msamples/s (output channel-samples)",
@@ -356,22 +532,63 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32" if s == 4 else "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "channels": C, "taps": taps, "partition": L,
+            "config": {"workload": args.workload, "channels": C_all, "taps": taps, "partition": L,
                        "fft_size": N, "partitions": B, "blocks_per_step": nb,
-                       "blocks_per_launch": args.chunk, "engines_rank0": n_eng,
-                       "streams_total": args.streams if args.streams > 0 else world,
-                       "io": "interleaved frames resident in HBM",
-                       "parallelism": "independent engines per GPU, no collective"},
+                       "blocks_per_launch": chunk, "engines_rank0": n_eng, "channels_rank0": C,
+                       "streams_total": args.streams if args.streams > 0 else (1 if scaling == "strong" else world),
+                       "io": "interleaved frames resident in HBM (generated there)",
+                       "parallelism": mode + ", no collective"},
+            "timed_region_s": round(elapsed, 4),
             "per_gpu_value": round(value / world, 1),
             "pct_of_hbm_roofline_algorithmic": round(
-                100.0 * (value / world * 1e6) * (sum(alg.values()) / (L * C)) / (HBM_PEAK_GBS * 1e9), 2),
+                100.0 * (value / world * 1e6) * (sum(algorithmic_bytes_per_block(C_all, B, N, L, s).values()) / (L * C_all))
+                / (HBM_PEAK_GBS * 1e9), 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity_rel_err_vs_oracle": parity,
+            "parity_checked": parity_note,
         }
+        result.update(extras)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def host_path_figures(bfir, torch, L, B, s, C, h, d_in, local):
+    """end_to_end: the host-pointer entry (bfir_engine_run: pageable host buffers -> pinned staging ->
+    H2D -> kernels -> D2H -> host), PCIe inclusive, on a bounded sample.  latency_one_block_us: one
+    run() per L-frame block, the plug-in's call pattern (foo_dsp_bfir/foo_dsp_bfir.cpp:311-349)."""
+    out = {}
+    try:
+        nbh = min(d_in.shape[1] // L, 2048)
+        x = d_in[0, :nbh * L].cpu().numpy()
+        e = bfir.Brutefir(L, B, s, C, device=local)
+        assert e.set_coeff(h) == 0
+        y = np.empty_like(x)
+        e.run(x, y)                                        # allocates the staging buffers
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            rc, _ = e.run(x, y)
+            assert rc == 0
+        dt = (time.perf_counter() - t0) / reps
+        out["end_to_end"] = {"value": round(nbh * L * C / dt / 1e6, 1), "unit": "Msamples/s",
+                             "what": "bfir_engine_run on host buffers, PCIe and host staging copies inclusive",
+                             "sample": "%d blocks per call, mean of %d calls" % (nbh, reps)}
+        lat = []
+        for t in range(min(nbh, 300)):
+            blk = x[t * L:(t + 1) * L]
+            t0 = time.perf_counter()
+            rc, _ = e.run(blk, y[:L])
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat[20:]) * 1e6
+        out["latency_one_block_us"] = {"median": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1),
+                                       "what": "one bfir_engine_run of one %d-frame block of %d channels, host to host" % (L, C),
+                                       "calls": int(lat.size)}
+        e.close()
+    except Exception as exc:   # never cost the bench line
+        out["host_path_error"] = repr(exc)
+    return out
 
 
 if __name__ == "__main__":

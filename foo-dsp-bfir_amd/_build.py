@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbfir_hip.so")
-SOURCES = ["kernels.hip", "engine.hip", "stage.hip", "bigfft.hip", "pair.hip"]
+SOURCES = ["kernels.hip", "engine.hip", "stage.hip", "bigfft.hip", "pair.hip", "dither.hip"]
 HEADERS = ["kernels.h", "fft_lds.h", os.path.join("..", "..", "include", "bfir_hip.h")]
 # -ffp-contract=on: fuse only inside one source expression (the stage kernels rely on it);
 # -fno-slp-vectorize: packing the FFT butterflies into v_pk_* costs more moves than it saves

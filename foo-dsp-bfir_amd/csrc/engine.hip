@@ -130,6 +130,10 @@ struct bfir_engine {
     FftPlan plan2;                         // transform of 2L complex points
     float *tails[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     const float *hist_raw[2] = {nullptr, nullptr};
+    // HP-TPDF dither (integer output + apply_dither; dither.hip): the reference instance's random table
+    // (every engine of a batch would build the same one) and dither_state_t per global channel
+    int8_t *d_dither_tab = nullptr; int dither_size = 0;
+    DevDitherState *d_dither_state = nullptr;
     bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
@@ -221,7 +225,6 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
                                                  int out_format, int sampling_rate, int apply_dither,
                                                  int device, int *err)
 {
-    (void)sampling_rate;
     int dummy;
     if (!err) err = &dummy;
     *err = BFIR_OK;
@@ -236,10 +239,6 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     }
     if (filter_blocks < 1 || n_engines < 1) { *err = BFIR_ERR_ARG; return nullptr; }
     if (!fmt_bytes(in_format) || !fmt_bytes(out_format)) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
-    // Dither only ever acts on integer outputs (fftw_convolver.cpp:421).  The reference's own
-    // dither path cannot run: dither_preloop_real2int_hp_tpdf is empty (dither.cpp:190-194), so
-    // dither_state_t.randtab stays NULL and real2int_hp_tpdf dereferences it.  Refused, not emulated.
-    if (apply_dither && !fmt_info(out_format).isfloat) { *err = BFIR_ERR_UNSUPPORTED; return nullptr; }
     int ndev = bfir_device_count();
     if (ndev <= 0) { *err = BFIR_ERR_NO_DEVICE; return nullptr; }
     if (device < 0 || device >= ndev) { *err = BFIR_ERR_ARG; return nullptr; }
@@ -306,6 +305,23 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     (void)hipMemset(e->d_nblk, 0, sizeof(int) * e->GC);
     (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
     (void)hipMemset(e->d_bad, 0x7f, sizeof(int));
+    if (apply_dither && !fmt_info(out_format).isfloat) {
+        // dither::dither(n_channels, sampling_rate, realsize, max_dither_table_size = 0, filter_length, state)
+        // as brutefir::init_convolver builds it (brutefir.cpp:709-714)
+        const int spacing = dither_spacing(channels, sampling_rate, 0, filter_length);
+        if (spacing < 0) return fail(BFIR_ERR_ARG);
+        std::vector<int8_t> tab;
+        dither_fill_table(tab, channels, spacing);
+        std::vector<DevDitherState> st((size_t)e->GC);
+        for (int gc = 0; gc < e->GC; gc++) { memset(&st[gc], 0, sizeof(DevDitherState)); st[gc].randtab_ptr = (gc % channels) * spacing + 1; }
+        if (hipMalloc((void **)&e->d_dither_tab, tab.size()) != hipSuccess ||
+            hipMalloc((void **)&e->d_dither_state, st.size() * sizeof(DevDitherState)) != hipSuccess ||
+            hipMemcpy(e->d_dither_tab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(e->d_dither_state, st.data(), st.size() * sizeof(DevDitherState), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(BFIR_ERR_HIP);
+        e->dither_size = (int)tab.size();
+        bfir_logf("Dither table size is %d bytes.", e->dither_size);
+    }
     if (alloc_work(e, 1) != BFIR_OK) return fail(BFIR_ERR_HIP);
     if (hipDeviceSynchronize() != hipSuccess) return fail(BFIR_ERR_HIP);
     bfir_logf("bfir engine: %d x %d channels, partition %d, %d blocks, realsize %d on device %d.",
@@ -330,7 +346,7 @@ extern "C" void bfir_engine_destroy(bfir_engine *e)
     fft_plan_destroy(&e->plan);
     fft_plan_destroy(&e->plan2);
     for (int st = 0; st < 2; st++) for (int i = 0; i < 2; i++) if (e->tails[st][i]) (void)hipFree(e->tails[st][i]);
-    void *bufs[] = {e->H, e->saved[0], e->saved[1], e->d_nblk, e->d_of, e->d_bad};
+    void *bufs[] = {e->H, e->saved[0], e->saved[1], e->d_nblk, e->d_of, e->d_bad, e->d_dither_tab, e->d_dither_state};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto &sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -663,6 +679,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.src = e->tout; a.src_ch_stride = t_stride;
         a.realsize = e->s; a.L = e->L; a.max = e->of_max;
         a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.dither_tab = e->d_dither_tab; a.dither_size = e->dither_size; a.dither_state = e->d_dither_state;
         launch_stage_out(a, st);
     }
     // input_timecbuf bookkeeping: block j of the chunk lands in buffer

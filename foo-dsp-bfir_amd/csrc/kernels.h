@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace bfir {
 
 // Per-channel output statistics kept on the device; folded into
@@ -69,8 +71,17 @@ struct StageOutArgs {
     int *bad_block;                // atomicMin of the first block with a non-finite sample 0
     int block_base;                // index of the chunk's first block within the run
     int fmt = 0;                   // BF_SAMPLE_FORMAT_* code; 0 = FLOAT_LE / FLOAT64_LE by raw_bytes
+    // HP-TPDF dither (integer formats only, dither.hip): the shared random table and one state per global channel
+    const void *dither_tab = nullptr; int dither_size = 0; void *dither_state = nullptr;
 };
 void launch_stage_out(const StageOutArgs &a, hipStream_t s);
+
+// dither_state_t (brutefir/global.h:63-69) as the engine keeps it in HBM, one per global channel
+struct DevDitherState { int randtab_ptr; int pad; float sf[2]; double sd[2]; };
+// class dither's table (brutefir/dither.cpp:21-110): spacing between channels in samples (-1: budget too small)
+int dither_spacing(int n_channels, int sample_rate, int max_size, int max_samples_per_loop);
+void dither_fill_table(std::vector<int8_t> &tab, int n_channels, int spacing);
+void launch_stage_out_dither(const StageOutArgs &a, hipStream_t s);
 
 // a6 + a7 (and a16 with zero_first_half): real FFT of the N-sample window
 // [block t-1 | block t] of channel gc, written in the grouped layout to

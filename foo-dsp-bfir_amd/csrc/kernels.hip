@@ -941,8 +941,9 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int 
 // ngrp: groups of PB blocks per wave (BFIR_MAC_RANGE overrides, in blocks)
 template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStream_t s)
 {
-    static int range_env = -1;
-    if (range_env < 0) { const char *e = getenv("BFIR_MAC_RANGE"); range_env = e ? atoi(e) : 0; }
+    // read per launch (a getenv is nanoseconds next to a launch) so tests can switch it in-process
+    const char *re_ = getenv("BFIR_MAC_RANGE");
+    const int range_env = re_ ? atoi(re_) : 0;
     const int ncol = a.N / 2 / 256;                      // workgroup columns of 256 bins
     int ngrp;
     if (range_env > 0) ngrp = std::max(1, range_env / PB);
@@ -1002,7 +1003,7 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         const int v = mac_variant();
         // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns
         const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
-        static const bool batched_only = getenv("BFIR_MAC_BATCHED") != nullptr;   // tuning aid
+        const bool batched_only = getenv("BFIR_MAC_BATCHED") != nullptr;   // tuning aid / test hook, read per launch
         if (a.interleaved && a.B > 32 && tt >= 32 && !batched_only) {
             // more partitions than one register batch: the LDS-shared kernel on the pair layout beats
             // re-reading X and Y once per batch of 32 (profiles/r01_other_configs.txt)
@@ -1331,6 +1332,7 @@ template <typename T> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_o
 void launch_stage_out(const StageOutArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
+    if (a.dither_tab && !fmt_info(a.fmt).isfloat) { launch_stage_out_dither(a, s); return; }   // fftw_convolver.cpp:421, 444
     if (a.fmt != 0 && !fmt_is_native(a.fmt)) {
         const FmtInfo fi = fmt_info(a.fmt);
         const long nb = (a.n_frames + 4 * STAGE_THREADS - 1) / (4 * STAGE_THREADS);

@@ -275,6 +275,34 @@ extern "C" int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void
     return BFIR_OK;
 }
 
+int bfir_dither_run_block(bfir_dither *d, const void *d_src, void *d_raw, int fmt, int spacing, int n,
+                          bfir_dither_state *state, bfir_overflow *overflow, hipStream_t s);   // dither.hip
+
+extern "C" int bfir_convolver_cbuf2raw_dither(bfir_convolver *c, bfir_dither *d, const void *cbuf, void *outbuf,
+                                              const bfir_buffer_format *bf, bfir_dither_state *dither_state,
+                                              bfir_overflow *overflow)
+{
+    if (!c || !cbuf || !outbuf || !overflow) return BFIR_ERR_ARG;
+    int rc = check_bf(bf);
+    if (rc != BFIR_OK) return rc;
+    if (bf->sf.isfloat) return bfir_convolver_cbuf2raw(c, cbuf, outbuf, bf, overflow);   // fftw_convolver.cpp:421
+    if (!d || !dither_state) { bfir_logf("Dither instance not set."); return BFIR_ERR_ARG; }   // :412-416
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t span = ((size_t)(c->L - 1) * bf->sample_spacing + 1) * bf->sf.bytes;
+    rc = need_raw(c, span);
+    if (rc != BFIR_OK) return rc;
+    char *dst = (char *)outbuf + bf->byte_offset;
+    HIP_TRY(hipMemcpyAsync(c->d_raw, dst, span, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d[0], cbuf, (size_t)c->L * c->s, hipMemcpyHostToDevice, c->stream));
+    bfir_dither_preloop_real2int_hp_tpdf(d, dither_state, c->L);
+    rc = bfir_dither_run_block(d, c->d[0], c->d_raw, bf->sf.format, bf->sample_spacing, c->L, dither_state, overflow,
+                               c->stream);
+    if (rc != BFIR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, c->d_raw, span, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFIR_OK;
+}
+
 extern "C" void *bfir_convolver_coeffs2cbuf(bfir_convolver *c, const void *coeffs, int n_coeffs,
                                             double scale, void *optional_dest)
 {

@@ -102,9 +102,10 @@ typedef struct bfir_engine bfir_engine;
  * filter_length: partition length L (power of two, 16..16384; 8192 max for
  * realsize 8); filter_blocks: B; realsize: 4 or 8; channels: 1..8;
  * in/out_format: any BFIR_SAMPLE_FORMAT_* code (FLOAT_LE / FLOAT64_LE take the
- * vectorised staging kernels, the others a byte-wise one); apply_dither with an
- * integer output format is refused (the reference's dither path dereferences a
- * table pointer it never sets, dither.cpp:190-194).  device: HIP ordinal.
+ * vectorised staging kernels, the others a byte-wise one); apply_dither acts on
+ * integer output formats only (fftw_convolver.cpp:421, 444): HP-TPDF dither with
+ * the reference's random table (dither.cpp:21-110; sampling_rate sizes it) and
+ * error feedback, one lane per channel.  device: HIP ordinal.
  * Returns NULL and sets *err on failure. */
 bfir_engine *bfir_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
                                 int in_format, int out_format, int sampling_rate, int apply_dither,
@@ -195,9 +196,31 @@ int bfir_convolver_convolve_add(bfir_convolver *c, const void *input_cbuf, const
                                 void *output_cbuf);
 /* convolver_freq2time (:350-375): FFTW_HC2R */
 int bfir_convolver_freq2time(bfir_convolver *c, const void *input_cbuf, void *output_cbuf);
-/* convolver_cbuf2raw (:405-466), no dither, float formats */
+/* convolver_cbuf2raw (:405-466) with apply_dither false (or a float format): any sample format */
 int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void *outbuf,
                             const bfir_buffer_format *bf, bfir_overflow *overflow);
+
+/* class dither (brutefir/dither.hpp:13-77, dither.cpp) and dither_state_t (global.h:63-69, same
+ * layout).  The constructor fills dither_state[0 .. n_channels) as the reference's does. */
+typedef struct bfir_dither bfir_dither;
+typedef struct bfir_dither_state {
+    int randtab_ptr;
+    int8_t *randtab;
+    float sf[2];
+    double sd[2];
+} bfir_dither_state;
+bfir_dither *bfir_dither_create(int n_channels, int sample_rate, int realsize, int max_size,
+                                int max_samples_per_loop, bfir_dither_state *dither_state, int device, int *err);
+void bfir_dither_destroy(bfir_dither *d);
+int bfir_dither_table_size(const bfir_dither *d);
+const int8_t *bfir_dither_table(const bfir_dither *d);   /* host copy of dither_randtab */
+/* dither::dither_preloop_real2int_hp_tpdf (dither.cpp:127-139) */
+void bfir_dither_preloop_real2int_hp_tpdf(bfir_dither *d, bfir_dither_state *state, int samples_per_loop);
+/* convolver_cbuf2raw with apply_dither true on an integer format (:421-431, :444-454): the preloop
+ * for n_fft2 samples, then real2raw{f,d}_hp_tpdf with the caller's dither_state and overflow */
+int bfir_convolver_cbuf2raw_dither(bfir_convolver *c, bfir_dither *d, const void *cbuf, void *outbuf,
+                                   const bfir_buffer_format *bf, bfir_dither_state *dither_state,
+                                   bfir_overflow *overflow);
 /* convolver_coeffs2cbuf (:474-537).  Returns optional_dest, or (when it is
  * NULL) a 16-byte aligned host block the CALLER frees with bfir_aligned_free
  * (the reference caller frees it with _aligned_free, brutefir.cpp:844-854);

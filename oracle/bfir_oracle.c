@@ -36,6 +36,20 @@ double orc_fmt_in_scale(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : 1.0 / orc
 double orc_fmt_out_scale(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_scale(fmt); }
 double orc_fmt_max(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_scale(fmt) - 1.0; }
 
+/* ------------------------------------------------------------------ */
+/* HP-TPDF dither: class dither (brutefir/dither.cpp)                   */
+/* ------------------------------------------------------------------ */
+/* dither_randmap (dither.cpp:73-104): difference of two table bytes -> dither value in [-1, +1]
+ * plus the +0.5 of the mid-tread requantiser; evaluated in double as there, narrowed by the
+ * caller.  Entries -256 and 254 are set exactly; +255 lies one past the reference's table (see
+ * bfir_oracle.h) and takes the formula's continuation. */
+static double orc_dither_map(int d)
+{
+    if (d <= -256) return -0.5;
+    if (d == 254) return 1.5;
+    return 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (double)d;
+}
+
 #define REAL float
 #define SUF(x) x##_f
 #include "bfir_oracle_impl.inc"
@@ -188,6 +202,102 @@ void orc_equalizer_render_d(int taps, int band_count, const double *freq, const 
 
 #define ORC_MAXCH 8 /* BF_MAXCHANNELS, brutefir/global.h:21 */
 
+
+/* One dither_state_t (brutefir/global.h:63-69). */
+typedef struct {
+    int randtab_ptr;
+    const int8_t *randtab;
+    float sf[2];
+    double sd[2];
+} orc_dither_state;
+
+struct orc_dither {
+    int8_t *tab;
+    int size, realsize, n_channels;
+    orc_dither_state st[ORC_MAXCH];
+};
+
+/* Combined Tausworthe generator of dither.cpp:419-435 (its TAUSWORTHE macro spelled out per
+ * component: mask c, shifts a, b, d). */
+static uint32_t taus_step(uint32_t s, int a, int b, uint32_t c, int d)
+{
+    return ((s & c) << d) ^ (((s << a) ^ s) >> b);
+}
+
+static uint32_t taus_next(uint32_t st[3])
+{
+    st[0] = taus_step(st[0], 13, 19, 4294967294u, 12);
+    st[1] = taus_step(st[1], 2, 25, 4294967288u, 4);
+    st[2] = taus_step(st[2], 3, 11, 4294967280u, 17);
+    return st[0] ^ st[1] ^ st[2];
+}
+
+/* tausinit (dither.cpp:437-449): seed 0 means 1; three LCG steps (69069 n mod 2^32), six warm-up draws */
+static void taus_seed(uint32_t st[3], uint32_t seed)
+{
+    int i;
+    if (seed == 0) seed = 1;
+    st[0] = 69069u * seed;
+    st[1] = 69069u * st[0];
+    st[2] = 69069u * st[1];
+    for (i = 0; i < 6; i++) (void)taus_next(st);
+}
+
+orc_dither *orc_dither_create(int n_channels, int sample_rate, int realsize, int max_size, int max_samples_per_loop)
+{
+    /* dither.cpp:29-60: channels sit RANDTAB_SPACING = 10 s apart in the table, never closer than
+     * max(1 s, one loop); an explicit byte budget may shrink the spacing down to that minimum */
+    orc_dither *d;
+    uint32_t st[3];
+    int n, spacing = 10 * sample_rate;
+    const int minspacing = (sample_rate > max_samples_per_loop) ? sample_rate : max_samples_per_loop;
+    if (n_channels < 1 || n_channels > ORC_MAXCH || (realsize != 4 && realsize != 8)) return NULL;
+    if (spacing < minspacing) spacing = minspacing;
+    if (max_size > 0 && n_channels * spacing > max_size) spacing = max_size / n_channels;
+    if (spacing < minspacing) return NULL;                       /* the reference throws here */
+    d = (orc_dither *)calloc(1, sizeof(*d));
+    d->size = n_channels * spacing + 1;                          /* :62 */
+    d->realsize = realsize; d->n_channels = n_channels;
+    d->tab = (int8_t *)malloc((size_t)d->size);
+    taus_seed(st, 0);                                            /* :67 */
+    for (n = 0; n < d->size; n++) d->tab[n] = (int8_t)(taus_next(st) & 0xFFu);   /* :71-74 */
+    for (n = 0; n < n_channels; n++) d->st[n].randtab_ptr = n * spacing + 1;     /* :105-109 */
+    return d;
+}
+
+void orc_dither_destroy(orc_dither *d) { if (d) { free(d->tab); free(d); } }
+int orc_dither_table_size(const orc_dither *d) { return d->size; }
+const int8_t *orc_dither_table(const orc_dither *d) { return d->tab; }
+int orc_dither_randtab_ptr(const orc_dither *d, int channel) { return d->st[channel].randtab_ptr; }
+
+/* dither_preloop_real2int_hp_tpdf (dither.cpp:127-139): at the end of the table carry the last
+ * byte used into slot 0 (the table is shared, slot 0 really is overwritten) and start over. */
+static void dither_preloop(orc_dither *d, orc_dither_state *st, int samples_per_loop)
+{
+    if (st->randtab_ptr + samples_per_loop >= d->size) {
+        d->tab[0] = d->tab[st->randtab_ptr - 1];
+        st->randtab_ptr = 1;
+    }
+    st->randtab = d->tab + st->randtab_ptr;
+    st->randtab_ptr += samples_per_loop;
+}
+
+void orc_real2raw_hp_tpdf_f(orc_dither *d, int channel, void *raw, const float *real, int fmt, int spacing, int n,
+                            orc_overflow_t *of)
+{
+    orc_dither_state *st = &d->st[channel];
+    dither_preloop(d, st, n);
+    real2raw_hp_tpdf_f(raw, real, fmt, spacing, n, of, st->sf, st->randtab);
+}
+
+void orc_real2raw_hp_tpdf_d(orc_dither *d, int channel, void *raw, const double *real, int fmt, int spacing, int n,
+                            orc_overflow_t *of)
+{
+    orc_dither_state *st = &d->st[channel];
+    dither_preloop(d, st, n);
+    real2raw_hp_tpdf_d(raw, real, fmt, spacing, n, of, st->sd, st->randtab);
+}
+
 /* State of one brutefir instance (brutefir/brutefir.hpp:96-127), kept as
  * untyped byte buffers whose element type follows realsize. */
 struct orc_engine {
@@ -206,12 +316,20 @@ struct orc_engine {
     uint8_t *ifreq, *ofreq, *tout;
     orc_overflow_t overflow[ORC_MAXCH];
     int initialized;
+    orc_dither *dither;              /* m_dither; always built (brutefir.cpp:709-714) */
+    int apply_dither;                /* bfconf->outputs[n].apply_dither               */
 };
 
 static int fmt_bytes(int fmt) { return orc_fmt_bytes(fmt); }
 
 orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
                               int in_format, int out_format)
+{
+    return orc_engine_create_ex(filter_length, filter_blocks, realsize, channels, in_format, out_format, 44100, 0);
+}
+
+orc_engine *orc_engine_create_ex(int filter_length, int filter_blocks, int realsize, int channels,
+                                 int in_format, int out_format, int sampling_rate, int apply_dither)
 {
     orc_engine *e;
     int n, lg = 0;
@@ -227,6 +345,10 @@ orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize
     e->s = realsize; e->C = channels;
     e->in_bytes = fmt_bytes(in_format); e->out_bytes = fmt_bytes(out_format);
     e->in_fmt = in_format; e->out_fmt = out_format;
+    /* init_convolver (brutefir.cpp:709-714): max_dither_table_size is never set (bfconf is zeroed, :31-32) */
+    e->apply_dither = apply_dither;
+    e->dither = orc_dither_create(channels, sampling_rate, realsize, 0, filter_length);
+    if (!e->dither) { free(e); return NULL; }
     /* setup_input: normalised scale; setup_output: full scale (brutefir.cpp:546-582) */
     e->in_scale = orc_fmt_in_scale(in_format); e->out_scale = orc_fmt_out_scale(out_format);
     cb = (size_t)e->N * (size_t)e->s;                           /* convolver_cbufsize */
@@ -263,6 +385,7 @@ void orc_engine_destroy(orc_engine *e)
         free(e->fdl[n]); free(e->timebuf[n][0]); free(e->timebuf[n][1]);
     }
     free(e->ifreq); free(e->ofreq); free(e->tout);
+    orc_dither_destroy(e->dither);
     free(e);
 }
 
@@ -399,7 +522,14 @@ int orc_engine_run(orc_engine *e, const void *inbuf, void *outbuf)
         }
         if (!finite) return -1;
         /* :326-334 staging out: the first L samples are the valid half */
-        if (e->s == 4)
+        if (e->apply_dither && !orc_fmt_isfloat(e->out_fmt)) {     /* fftw_convolver.cpp:421, 444 */
+            if (e->s == 4)
+                orc_real2raw_hp_tpdf_f(e->dither, n, (uint8_t *)outbuf + n * e->out_bytes, (const float *)e->tout,
+                                       e->out_fmt, e->C, e->L, &e->overflow[n]);
+            else
+                orc_real2raw_hp_tpdf_d(e->dither, n, (uint8_t *)outbuf + n * e->out_bytes, (const double *)e->tout,
+                                       e->out_fmt, e->C, e->L, &e->overflow[n]);
+        } else if (e->s == 4)
             orc_real2raw_fmt_f((uint8_t *)outbuf + n * e->out_bytes, (const float *)e->tout,
                                e->out_fmt, e->C, e->L, &e->overflow[n]);
         else

@@ -108,6 +108,35 @@ void orc_raw2real_fmt_d(double *real, const void *raw, int fmt, int spacing, int
 void orc_real2raw_fmt_f(void *raw, const float *real, int fmt, int spacing, int n, orc_overflow_t *of);
 void orc_real2raw_fmt_d(void *raw, const double *real, int fmt, int spacing, int n, orc_overflow_t *of);
 
+/* ---- HP-TPDF dither on integer outputs: brutefir/dither.cpp ----
+ * orc_dither restates class dither: the table of int8 random numbers drawn from the combined
+ * Tausworthe generator seeded with tausinit(state, 0) (dither.cpp:21-110, 419-449), the
+ * difference -> float map (:73-104) and the per-channel state dither_state_t (global.h:63-69:
+ * table position, two error-feedback memories).  Nothing here reads a reference output: the
+ * generator is the published GSL "taus" recurrence the reference cites, restated from
+ * dither.cpp's macros; PARITY UNPINNED like the rest of this oracle.
+ * One quirk is undefined in the reference and defined here: the map has entries -256 .. 254,
+ * but the difference of two int8 values reaches +255 (127 - (-128)), where the reference reads
+ * one element past its 511-entry allocation (dither.cpp:176-178).  Oracle and HIP engine both
+ * use the table formula's continuation there, 0.5 + 1/255 + 255/255. */
+typedef struct orc_dither orc_dither;
+/* dither::dither(n_channels, sample_rate, realsize, max_size, max_samples_per_loop, state[])
+ * (dither.cpp:21-110).  NULL where the reference throws (table budget too small). */
+orc_dither *orc_dither_create(int n_channels, int sample_rate, int realsize, int max_size,
+                              int max_samples_per_loop);
+void orc_dither_destroy(orc_dither *d);
+int orc_dither_table_size(const orc_dither *d);
+const int8_t *orc_dither_table(const orc_dither *d);
+int orc_dither_randtab_ptr(const orc_dither *d, int channel);
+/* convolver_cbuf2raw with apply_dither on an integer format (fftw_convolver.cpp:421-431, 444-454):
+ * dither_preloop_real2int_hp_tpdf (dither.cpp:127-139) for n samples of `channel`, then
+ * real2raw{f,d}_hp_tpdf (real2raw.cpp:38-317, 422-...) with dither{f,d}_real2int_hp_tpdf
+ * (dither.cpp:141-194, 264-344) per sample. */
+void orc_real2raw_hp_tpdf_f(orc_dither *d, int channel, void *raw, const float *real, int fmt, int spacing,
+                            int n, orc_overflow_t *of);
+void orc_real2raw_hp_tpdf_d(orc_dither *d, int channel, void *raw, const double *real, int fmt, int spacing,
+                            int n, orc_overflow_t *of);
+
 /* ---- boundary features nothing in the tree calls ---- */
 /* mixnscale with n_bufs >= 1 (fftw_convolver.cpp:908-1156, 1187-1419). */
 void orc_mixnscale_n_f(int n_fft, const float *const *ins, float *out, const double *scales, int n_bufs, int mixmode);
@@ -140,6 +169,10 @@ typedef struct orc_engine orc_engine;
  * outside 1..8, format not FLOAT_LE / FLOAT64_LE). */
 orc_engine *orc_engine_create(int filter_length, int filter_blocks, int realsize, int channels,
                               int in_format, int out_format);
+/* the full argument list of the reference constructor: sampling_rate sizes the dither table
+ * (brutefir.cpp:709-714), apply_dither selects real2raw_hp_tpdf for integer outputs (:326-331) */
+orc_engine *orc_engine_create_ex(int filter_length, int filter_blocks, int realsize, int channels,
+                                 int in_format, int out_format, int sampling_rate, int apply_dither);
 void orc_engine_destroy(orc_engine *e);
 
 /* brutefir::set_coeff(void**, ...) (brutefir/brutefir.cpp:179-228) with

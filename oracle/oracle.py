@@ -63,6 +63,12 @@ def lib():
             "orc_real2raw_f": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
             "orc_real2raw_d": (None, [vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
             "orc_engine_create": (vp, [ci, ci, ci, ci, ci, ci]),
+            "orc_engine_create_ex": (vp, [ci, ci, ci, ci, ci, ci, ci, ci]),
+            "orc_dither_create": (vp, [ci, ci, ci, ci, ci]), "orc_dither_destroy": (None, [vp]),
+            "orc_dither_table_size": (ci, [vp]), "orc_dither_table": (vp, [vp]),
+            "orc_dither_randtab_ptr": (ci, [vp, ci]),
+            "orc_real2raw_hp_tpdf_f": (None, [vp, ci, vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
+            "orc_real2raw_hp_tpdf_d": (None, [vp, ci, vp, vp, ci, ci, ci, C.POINTER(Overflow)]),
             "orc_engine_destroy": (None, [vp]),
             "orc_engine_set_coeff": (ci, [vp, C.POINTER(vp), ci, ci, ci, cd]),
             "orc_engine_run": (ci, [vp, vp, vp]),
@@ -286,18 +292,53 @@ def direct_conv(x, h):
     return y
 
 
+class Dither:
+    """class dither (brutefir/dither.cpp): random table + per-channel state."""
+
+    def __init__(self, n_channels, sample_rate, realsize, max_size=0, max_samples_per_loop=1024):
+        self.realsize = realsize
+        self.h = lib().orc_dither_create(n_channels, sample_rate, realsize, max_size, max_samples_per_loop)
+        if not self.h:
+            raise ValueError("dither table budget too small")
+
+    def close(self):
+        if self.h:
+            lib().orc_dither_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def table(self):
+        n = lib().orc_dither_table_size(self.h)
+        buf = (C.c_int8 * n).from_address(lib().orc_dither_table(self.h))
+        return np.frombuffer(buf, dtype=np.int8, count=n).copy()
+
+    def randtab_ptr(self, channel):
+        return lib().orc_dither_randtab_ptr(self.h, channel)
+
+    def real2raw(self, real, raw, channel, fmt, of):
+        """convolver_cbuf2raw with apply_dither: preloop + real2raw_hp_tpdf of `real` into channel
+        `channel` of the interleaved integer buffer `raw`."""
+        real = np.ascontiguousarray(real, dtype=real_dtype(self.realsize))
+        base = raw.ctypes.data + channel * FMT_BYTES[fmt]
+        getattr(lib(), "orc_real2raw_hp_tpdf" + _suf(real.dtype))(self.h, channel, C.c_void_p(base), _p(real), fmt,
+                                                                   raw.shape[1], real.size, C.byref(of))
+
+
 # ---- engine level --------------------------------------------------------
 class Engine:
     """brutefir (brutefir/brutefir.hpp:15-128) restated on the CPU."""
 
     def __init__(self, filter_length, filter_blocks, realsize, channels,
-                 in_format=None, out_format=None):
+                 in_format=None, out_format=None, sampling_rate=44100, apply_dither=False):
         dflt = FMT_FLOAT_LE if realsize == 4 else FMT_FLOAT64_LE
         self.L, self.B, self.s, self.C = filter_length, filter_blocks, realsize, channels
         self.in_format = dflt if in_format is None else in_format
         self.out_format = dflt if out_format is None else out_format
-        self.h = lib().orc_engine_create(filter_length, filter_blocks, realsize, channels,
-                                         self.in_format, self.out_format)
+        self.h = lib().orc_engine_create_ex(filter_length, filter_blocks, realsize, channels,
+                                            self.in_format, self.out_format, sampling_rate,
+                                            int(bool(apply_dither)))
         if not self.h:
             raise ValueError("oracle rejected engine parameters")
 
@@ -360,3 +401,30 @@ def synth_ir(rng, channels, taps, dtype):
 def synth_audio(rng, frames, channels, dtype):
     """i.i.d. uniform [-1,1) like buffer::load_white_noise (brutefir/buffer.cpp:454-493)."""
     return rng.uniform(-1.0, 1.0, (frames, channels)).astype(dtype)
+
+
+# ---- sampled reference for long runs -----------------------------------------
+def sampled_reference(h, get_block, blocks, L, B, s, C, in_format=None, out_format=None):
+    # (float outputs only: with dither the output also depends on the whole past through the
+    # error feedback, so there is no finite window)
+    """Oracle output of selected blocks of an arbitrarily long run without running it whole.
+
+    A partitioned FIR has B blocks of memory: output block g is a function of input blocks
+    g-B .. g only (partition i pairs with the spectrum of [block g-i-1 | block g-i],
+    brutefir/brutefir.cpp:288-299), and the sums of a fresh engine fed exactly those B+1 blocks
+    are the very sums of the long run (the one extra leading block supplies the "previous block"
+    half of the oldest spectrum that is used).  get_block(g) -> [L, C] input frames of global
+    block g (g < 0: the engine's zeroed start-up state, never requested).
+    Returns {g: [L, C] output frames}.
+    """
+    out = {}
+    for g in blocks:
+        g0 = max(0, g - B)
+        x = np.concatenate([get_block(k) for k in range(g0, g + 1)])
+        eng = Engine(L, B, s, C, in_format, out_format)
+        assert eng.set_coeff(h) == 0
+        rc, y = eng.run(x)
+        assert rc == 0
+        out[g] = y[-L:]
+        eng.close()
+    return out

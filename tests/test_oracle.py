@@ -134,3 +134,20 @@ def test_engine_argument_checks(orc):
     for args in [(100, 2, 4, 2), (64, 2, 5, 2), (64, 2, 4, 9), (64, 0, 4, 2)]:
         with pytest.raises(ValueError):
             orc.Engine(*args)
+
+
+def test_sampled_reference_equals_the_long_run(orc):
+    """oracle.sampled_reference (used for launches too long to run whole on the CPU): a fresh engine
+    fed the B+1 blocks ending at block g reproduces block g of the long run bit for bit."""
+    L, B, C, nb = 64, 5, 3, 23
+    rng = np.random.default_rng(12)
+    for s in (4, 8):
+        dt = orc.real_dtype(s)
+        h = orc.synth_ir(rng, C, B * L - 9, dt)
+        x = orc.synth_audio(rng, nb * L, C, dt)
+        eng = orc.Engine(L, B, s, C); eng.set_coeff(h)
+        _, y = eng.run(x)
+        pts = [0, 1, B - 1, B, B + 1, 17, nb - 1]
+        ref = orc.sampled_reference(h, lambda g: x[g * L:(g + 1) * L], pts, L, B, s, C)
+        for g in pts:
+            assert np.array_equal(ref[g], y[g * L:(g + 1) * L])

@@ -6,13 +6,13 @@ from . import _build
 from ._lib import (ERR_ARG, ERR_COEFF, ERR_HIP, ERR_NO_DEVICE, ERR_NONFINITE, ERR_STATE,
                    ERR_UNSUPPORTED, BfirError, BufferFormat, Overflow, SampleFormat, MIXMODE_INPUT, MIXMODE_OUTPUT,
                    SAMPLE_FORMAT_FLOAT64_LE, SAMPLE_FORMAT_FLOAT_LE, load, library_path)
-from .convolver import FftwConvolver
+from .convolver import Dither, FftwConvolver
 from .engine import Brutefir
 from .equalizer import Equalizer, FftPlan
 
 build = _build.build
 
-__all__ = ["Brutefir", "FftwConvolver", "Equalizer", "FftPlan", "BfirError", "BufferFormat", "Overflow", "SampleFormat",
+__all__ = ["Brutefir", "FftwConvolver", "Dither", "Equalizer", "FftPlan", "BfirError", "BufferFormat", "Overflow", "SampleFormat",
            "MIXMODE_INPUT", "MIXMODE_OUTPUT", "SAMPLE_FORMAT_FLOAT_LE", "SAMPLE_FORMAT_FLOAT64_LE",
            "build", "load", "library_path", "ERR_ARG", "ERR_COEFF", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_NONFINITE", "ERR_STATE", "ERR_UNSUPPORTED"]

@@ -23,12 +23,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS_FILE = os.path.join(LIBDIR, "flags.txt")
+
+
+def _flags_changed():
+    """The flags the objects in lib/ were built with are recorded beside them: a library built with
+    other flags (a -DBFIR_TRACE tuning build, an A/B variant) is stale for this build."""
+    try:
+        return open(FLAGS_FILE).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the shared library.
 
     hipcc cross-compiles without a GPU.  Returns the library path."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
+    force = force or _flags_changed()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for src in SOURCES:
@@ -50,7 +63,31 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
+
+
+def build_variant(name, extra_flags, verbose=False):
+    """Tuning aid: a second build of the library with extra hipcc flags (-D experiment switches) into
+    lib/variant_<name>/ -> lib/libbfir_hip_<name>.so, leaving the product library alone.  Select it for
+    one process with BFIR_LIB_OVERRIDE (A/B timing of two builds inside one gpurun call)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    vdir = os.path.join(LIBDIR, "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    flags = [f for f in FLAGS] + list(extra_flags)
+    objs, jobs = [], []
+    for src in SOURCES:
+        o = os.path.join(vdir, src.replace(".hip", ".o"))
+        jobs.append([hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        for r in pool.map(lambda c: subprocess.run(c, check=True), jobs):
+            pass
+    out = os.path.join(LIBDIR, "libbfir_hip_%s.so" % name)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-o", out] + objs, check=True)
+    return out
 
 
 if __name__ == "__main__":

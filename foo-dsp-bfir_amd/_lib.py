@@ -34,6 +34,12 @@ class BufferFormat(C.Structure):
     _fields_ = [("sf", SampleFormat), ("sample_spacing", C.c_int), ("byte_offset", C.c_int)]
 
 
+class DitherState(C.Structure):
+    """bfir_dither_state == dither_state_t (brutefir/global.h:63-69)."""
+    _fields_ = [("randtab_ptr", C.c_int), ("randtab", C.POINTER(C.c_int8)), ("sf", C.c_float * 2),
+                ("sd", C.c_double * 2)]
+
+
 LOG_FN = C.CFUNCTYPE(None, C.c_char_p)
 
 _vp, _ci, _cd, _cl = C.c_void_p, C.c_int, C.c_double, C.c_long
@@ -71,6 +77,13 @@ SIGNATURES = {
     "bfir_convolver_convolve_add": (_ci, [_vp, _vp, _vp, _vp]),
     "bfir_convolver_freq2time": (_ci, [_vp, _vp, _vp]),
     "bfir_convolver_cbuf2raw": (_ci, [_vp, _vp, _vp, C.POINTER(BufferFormat), C.POINTER(Overflow)]),
+    "bfir_dither_create": (_vp, [_ci, _ci, _ci, _ci, _ci, C.POINTER(DitherState), _ci, _pi]),
+    "bfir_dither_destroy": (None, [_vp]),
+    "bfir_dither_table_size": (_ci, [_vp]),
+    "bfir_dither_table": (C.POINTER(C.c_int8), [_vp]),
+    "bfir_dither_preloop_real2int_hp_tpdf": (None, [_vp, C.POINTER(DitherState), _ci]),
+    "bfir_convolver_cbuf2raw_dither": (_ci, [_vp, _vp, _vp, _vp, C.POINTER(BufferFormat), C.POINTER(DitherState),
+                                             C.POINTER(Overflow)]),
     "bfir_convolver_coeffs2cbuf": (_vp, [_vp, _vp, _ci, _cd, _vp]),
     "bfir_convolver_runtime_coeffs2cbuf": (_ci, [_vp, _vp, _vp]),
     "bfir_convolver_dirac_convolve": (_ci, [_vp, _vp, _vp]),

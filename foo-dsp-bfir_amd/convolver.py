@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BfirError, BufferFormat, Overflow
+from ._lib import BfirError, BufferFormat, DitherState, Overflow
 
 
 def make_buffer_format(fmt, channel, n_channels):
@@ -20,12 +20,43 @@ def make_buffer_format(fmt, channel, n_channels):
     return bf
 
 
-class FftwConvolver:
-    """fftw_convolver(length, realsize, dither) -- the dither object is not
-    needed for float outputs and is not taken."""
+class Dither:
+    """dither(n_channels, sample_rate, realsize, max_size, max_samples_per_loop, dither_state)
+    (brutefir/dither.hpp:13-77).  `states` is the dither_state_t array the reference keeps in
+    bfconf (global.h:87): the constructor fills it, the caller passes states[n] with channel n."""
 
-    def __init__(self, length, realsize, device=0):
+    def __init__(self, n_channels, sample_rate, realsize, max_size=0, max_samples_per_loop=1024, device=0):
         self._lib = _lib.load()
+        self.states = (DitherState * n_channels)()
+        err = C.c_int(0)
+        self._h = self._lib.bfir_dither_create(n_channels, sample_rate, realsize, max_size, max_samples_per_loop,
+                                               self.states, device, C.byref(err))
+        if not self._h:
+            raise BfirError(err.value, "bfir_dither_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bfir_dither_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self):
+        n = self._lib.bfir_dither_table_size(self._h)
+        return np.ctypeslib.as_array(self._lib.bfir_dither_table(self._h), shape=(n,)).copy()
+
+
+class FftwConvolver:
+    """fftw_convolver(length, realsize, dither) (brutefir/fftw_convolver.hpp:31).  `dither` (a Dither)
+    is only needed for convolver_cbuf2raw with apply_dither on an integer format."""
+
+    def __init__(self, length, realsize, dither=None, device=0):
+        self._lib = _lib.load()
+        self._dither = dither
         self.n_fft2, self.n_fft, self.realsize = length, 2 * length, realsize
         self.dtype = np.float32 if realsize == 4 else np.float64
         err = C.c_int(0)
@@ -88,7 +119,16 @@ class FftwConvolver:
         self._chk(self._lib.bfir_convolver_freq2time(self._h, self._buf(input_cbuf),
                                                      self._buf(output_cbuf)), "freq2time")
 
-    def convolver_cbuf2raw(self, cbuf, outbuf, bf, overflow):
+    def convolver_cbuf2raw(self, cbuf, outbuf, bf, overflow, apply_dither=False, dither_state=None):
+        """convolver_cbuf2raw(cbuf, outbuf, bf, apply_dither, dither_state, overflow)
+        (brutefir/fftw_convolver.cpp:405-466); dither only ever acts on integer formats."""
+        if apply_dither and not bf.sf.isfloat:
+            if self._dither is None or dither_state is None:
+                raise BfirError(_lib.ERR_ARG, "cbuf2raw: dither instance not set")     # :412-416
+            self._chk(self._lib.bfir_convolver_cbuf2raw_dither(self._h, self._dither._h, self._buf(cbuf),
+                                                               outbuf.ctypes.data, C.byref(bf),
+                                                               C.byref(dither_state), C.byref(overflow)), "cbuf2raw")
+            return
         self._chk(self._lib.bfir_convolver_cbuf2raw(self._h, self._buf(cbuf), outbuf.ctypes.data,
                                                     C.byref(bf), C.byref(overflow)), "cbuf2raw")
 

@@ -10,7 +10,7 @@
 // form (the quantiser sits inside it), so ONE LANE owns one channel and walks its samples in order;
 // channels are independent and share a wave.  Integer outputs are off the measured path.
 //
-// Undefined in the reference, defined here (same choice in the oracle): the map from byte
+// Undefined in the reference, defined here: the map from byte
 // differences to dither values has entries -256 .. 254 but a difference reaches +255, where the
 // reference reads one element past its table; we continue the table's formula.
 #include <hip/hip_runtime.h>

@@ -24,7 +24,12 @@ struct buffer_format_t {
     int sample_spacing;   // in samples
     int byte_offset;      // in bytes
 };
-struct dither_state_t;    // integer outputs only; never dereferenced on the float path
+struct dither_state_t {   // brutefir/global.h:63-69
+    int randtab_ptr;
+    int8_t *randtab;
+    float sf[2];
+    double sd[2];
+};
 struct bfoverflow_t {
     unsigned int n_overflows;
     int32_t intlargest;
@@ -35,6 +40,8 @@ struct bfoverflow_t {
 
 static_assert(sizeof(buffer_format_t) == sizeof(bfir_buffer_format), "buffer_format_t layout");
 static_assert(offsetof(buffer_format_t, byte_offset) == offsetof(bfir_buffer_format, byte_offset), "buffer_format_t layout");
+static_assert(sizeof(dither_state_t) == sizeof(bfir_dither_state), "dither_state_t layout");
+static_assert(offsetof(dither_state_t, sd) == offsetof(bfir_dither_state, sd), "dither_state_t layout");
 static_assert(sizeof(bfoverflow_t) == sizeof(bfir_overflow), "bfoverflow_t layout");
 static_assert(offsetof(bfoverflow_t, max) == offsetof(bfir_overflow, max), "bfoverflow_t layout");
 

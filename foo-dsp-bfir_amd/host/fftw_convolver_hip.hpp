@@ -12,30 +12,38 @@
 //  * coefficient blocks returned by convolver_coeffs2cbuf are freed with
 //    bfir_aligned_free (the reference caller uses _aligned_free,
 //    brutefir.cpp:844-854).
-//  * create_fft_plan returns an opaque token, not an FFTW plan; equalizer.cpp,
-//    which executes the plan with FFTW directly, is outside this path.
+//  * create_fft_plan returns a bfir_fft_plan* (an R2HC / HC2R plan of 2^order reals on the GPU), not an
+//    FFTW plan: a caller that executed it with fftw[f]_execute_r2r (equalizer.cpp:262, 357) calls
+//    bfir_fft_plan_execute(plan, in, out) instead.
 //  * convolver_debug_dump_cbuf (text-file dump) and the convolver_td_* family (used only
 //    by the dead `delay` class) are not provided.
 #pragma once
 #include <stdexcept>
 
-#include "bfir_types.hpp"
+#include <map>
 
-class dither;   // accepted for signature compatibility; float outputs never use it
+#include "bfir_types.hpp"
+#include "dither_hip.hpp"
 
 struct _td_conv_t_;
 typedef struct _td_conv_t_ td_conv_t;
 
 class fftw_convolver {
 public:
-    fftw_convolver(int length, int realsize, dither *dither_unused, int device = 0)
+    // fftw_convolver.cpp:51-138.  `dither` is borrowed (owned by brutefir, brutefir.cpp:53-54) and only
+    // used by convolver_cbuf2raw with apply_dither on an integer format.
+    fftw_convolver(int length, int realsize, dither *dither, int device = 0)
+        : m_dither(dither), m_realsize(realsize), m_device(device)
     {
-        (void)dither_unused;
         int err = 0;
         m_c = bfir_convolver_create(length, realsize, device, &err);
         if (!m_c) throw std::runtime_error(bfir_strerror(err));
     }
-    ~fftw_convolver() { bfir_convolver_destroy(m_c); }
+    ~fftw_convolver()
+    {
+        for (auto &kv : m_plans) bfir_fft_plan_destroy(kv.second);   // fftw_convolver.cpp:140-151
+        bfir_convolver_destroy(m_c);
+    }
     fftw_convolver(const fftw_convolver &) = delete;
     fftw_convolver &operator=(const fftw_convolver &) = delete;
 
@@ -75,12 +83,17 @@ public:
     {
         m_last = bfir_convolver_freq2time(m_c, input_cbuf, output_cbuf);
     }
-    // :405-466.  Dither applies to integer formats only (:421); float formats ignore the flag.
+    // :405-466.  Dither applies to integer formats only (:421, :444); a missing dither instance is the
+    // reference's "Dither instance not set." failure (:412-416).
     void convolver_cbuf2raw(void *cbuf, void *outbuf, struct buffer_format_t *bf, bool apply_dither,
                             struct dither_state_t *dither_state, struct bfoverflow_t *overflow)
     {
-        (void)apply_dither; (void)dither_state;
-        m_last = bfir_convolver_cbuf2raw(m_c, cbuf, outbuf, (const bfir_buffer_format *)bf, (bfir_overflow *)overflow);
+        if (apply_dither && !bf->sf.isfloat)
+            m_last = bfir_convolver_cbuf2raw_dither(m_c, m_dither ? m_dither->handle() : nullptr, cbuf, outbuf,
+                                                    (const bfir_buffer_format *)bf, (bfir_dither_state *)dither_state,
+                                                    (bfir_overflow *)overflow);
+        else
+            m_last = bfir_convolver_cbuf2raw(m_c, cbuf, outbuf, (const bfir_buffer_format *)bf, (bfir_overflow *)overflow);
     }
     // :468-472
     int convolver_cbufsize(void) { return bfir_convolver_cbufsize(m_c); }
@@ -114,15 +127,35 @@ public:
     // :569-602
     bool convolver_verify_cbuf(void *cbufs[], int n_cbufs) { return bfir_convolver_verify_cbuf(m_c, cbufs, n_cbufs) == 1; }
 
-    // :653-695: plans are device tables owned by the convolver; the token is only good
-    // for passing back to destroy_fft_plan.
-    void *create_fft_plan(int, int, int) { return m_c; }
-    void destroy_fft_plan(int, int, int) {}
+    // :653-695: a plan per (order, invert, inplace), created on first use, owned by the convolver.
+    // Returns a bfir_fft_plan* of 2^order reals: execute with bfir_fft_plan_execute(plan, in, out).
+    void *create_fft_plan(int order, int invert, int inplace)
+    {
+        const int key = (order << 2) | ((invert ? 1 : 0) << 1) | (inplace ? 1 : 0);
+        auto it = m_plans.find(key);
+        if (it != m_plans.end()) return it->second;
+        int err = 0;
+        bfir_fft_plan *p = bfir_fft_plan_create(order, invert ? 1 : 0, inplace ? 1 : 0, m_realsize, m_device, &err);
+        m_last = err;
+        if (p) m_plans[key] = p;
+        return p;
+    }
+    void destroy_fft_plan(int order, int invert, int inplace)
+    {
+        const int key = (order << 2) | ((invert ? 1 : 0) << 1) | (inplace ? 1 : 0);
+        auto it = m_plans.find(key);
+        if (it == m_plans.end()) return;
+        bfir_fft_plan_destroy(it->second);
+        m_plans.erase(it);
+    }
 
     // result of the last call (the reference's methods return void)
     int last_status() const { return m_last; }
 
 private:
     bfir_convolver *m_c = nullptr;
+    dither *m_dither = nullptr;
+    int m_realsize = 4, m_device = 0;
+    std::map<int, bfir_fft_plan *> m_plans;
     int m_last = BFIR_OK;
 };

@@ -193,6 +193,64 @@ int main()
         CHECK(std::fabs(d[0] - 1.0) < 1e-9 && std::fabs(d[1] - 1.0) < 1e-9 && rest < 1e-9, "flat EQ impulse %g %g rest %g", d[0], d[1], rest);
         remove(path.c_str());
     }
+    // dither (dither.cpp) through both classes: 16-bit output with HP-TPDF dither stays within the dither's
+    // reach of the undithered float result (y - x = e[n-1] - e[n-2] - e[n] with |e| <= 1.5 LSB), differs from the
+    // undithered integers, and the class fills dither_state as the reference's constructor does
+    {
+        const int L = 256, B = 2, C = 2, nb = 6, srate = 300;
+        std::mt19937 rng(11); std::uniform_real_distribution<float> u(-0.5f, 0.5f);
+        std::vector<float> h0(300), h1(300), x((size_t)nb * L * C), yf(x.size());
+        for (int n = 0; n < 300; n++) { h0[n] = u(rng) * 0.01f; h1[n] = u(rng) * 0.01f; }
+        h0[0] = 0.7f; h1[0] = -0.6f;
+        for (auto &v : x) v = u(rng);
+        void *hp[2] = {h0.data(), h1.data()};
+        std::vector<int16_t> yd(x.size()), yn(x.size());
+        brutefir ff(L, B, 4, C, BF_SAMPLE_FORMAT_FLOAT_LE, BF_SAMPLE_FORMAT_FLOAT_LE, srate, false);
+        brutefir fd(L, B, 4, C, BF_SAMPLE_FORMAT_FLOAT_LE, BFIR_SAMPLE_FORMAT_S16_LE, srate, true);
+        brutefir fn(L, B, 4, C, BF_SAMPLE_FORMAT_FLOAT_LE, BFIR_SAMPLE_FORMAT_S16_LE, srate, false);
+        CHECK(fd.create_error() == 0, "dither engine: %s", bfir_strerror(fd.create_error()));
+        ff.set_coeff(hp, C, 300, B, 1.0); fd.set_coeff(hp, C, 300, B, 1.0); fn.set_coeff(hp, C, 300, B, 1.0);
+        CHECK(ff.run_blocks(x.data(), yf.data(), nb) == 0 && fd.run_blocks(x.data(), yd.data(), nb) == 0 &&
+              fn.run_blocks(x.data(), yn.data(), nb) == 0, "dither runs");
+        double worst = 0; long differ = 0;
+        for (size_t i = 0; i < x.size(); i++) {
+            worst = std::max(worst, std::fabs((double)yd[i] - 32768.0 * yf[i]));
+            differ += yd[i] != yn[i];
+        }
+        CHECK(worst <= 4.6, "dithered output strays %.2f LSB from the float result", worst);
+        CHECK(differ > (long)x.size() / 10, "dither changed only %ld of %zu samples", differ, x.size());
+        dither_state_t st[BF_MAXCHANNELS];
+        dither dth(C, srate, 4, 0, L, st);
+        CHECK(st[0].randtab_ptr == 1 && st[1].randtab_ptr == 10 * srate + 1, "dither_state %d %d", st[0].randtab_ptr, st[1].randtab_ptr);
+        // the stage form: cbuf2raw with apply_dither on the same float block the engine produced
+        fftw_convolver conv(L, 4, &dth);
+        std::vector<float> cbuf(2 * L);
+        std::vector<int16_t> raw((size_t)L * C, 0);
+        buffer_format_t bf; bfoverflow_t of = {0, 0, 0.0, 32767.0};
+        bf.sf.isfloat = false; bf.sf.swap = false; bf.sf.bytes = bf.sf.sbytes = 2; bf.sf.scale = 1.0; bf.sf.format = BFIR_SAMPLE_FORMAT_S16_LE;
+        bf.sample_spacing = C; bf.byte_offset = 0;
+        for (int n = 0; n < L; n++) cbuf[n] = 32768.0f * yf[(size_t)n * C];
+        conv.convolver_cbuf2raw(cbuf.data(), raw.data(), &bf, true, &st[0], &of);
+        CHECK(conv.last_status() == 0, "cbuf2raw with dither: %s", bfir_strerror(conv.last_status()));
+        CHECK(st[0].randtab_ptr == 1 + L, "preloop must advance the table position: %d", st[0].randtab_ptr);
+        long same = 0;
+        for (int n = 0; n < L; n++) same += raw[(size_t)n * C] == yd[(size_t)n * C];
+        CHECK(same == L, "stage and engine dither disagree on %ld of %d samples", L - same, L);
+        fftw_convolver nod(L, 4, nullptr);
+        nod.convolver_cbuf2raw(cbuf.data(), raw.data(), &bf, true, &st[0], &of);
+        CHECK(nod.last_status() != 0, "cbuf2raw with dither but no dither instance must fail");
+        // create_fft_plan hands out a real plan (fftw_convolver.cpp:653-675): R2HC then HC2R is n times the input
+        void *fw = conv.create_fft_plan(9, 0, 0), *bw = conv.create_fft_plan(9, 1, 0);
+        CHECK(fw && bw && fw != bw && conv.create_fft_plan(9, 0, 0) == fw, "create_fft_plan");
+        std::vector<float> a(512), sp(512), b2(512);
+        for (auto &v : a) v = u(rng);
+        CHECK(bfir_fft_plan_execute((bfir_fft_plan *)fw, a.data(), sp.data()) == 0 &&
+              bfir_fft_plan_execute((bfir_fft_plan *)bw, sp.data(), b2.data()) == 0, "plan execute");
+        double e = 0;
+        for (int n = 0; n < 512; n++) e = std::max(e, std::fabs((double)b2[n] / 512.0 - a[n]));
+        CHECK(e < 1e-5, "plan round trip %g", e);
+        conv.destroy_fft_plan(9, 0, 0);
+    }
     printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -89,8 +89,11 @@ def test_engine_with_integer_and_big_endian_formats(orc, bfir, in_fmt, out_fmt, 
             assert abs(o.intlargest - r.intlargest) <= max(1, int(np.ceil(TOL[s] * abs(r.intlargest))))
 
 
-def test_dither_on_integer_output_is_refused(bfir):
-    with pytest.raises(bfir.BfirError) as ei:
-        bfir.Brutefir(256, 2, 4, 2, 2, 2, apply_dither=True)
-    assert ei.value.code == bfir.ERR_UNSUPPORTED
-    bfir.Brutefir(256, 2, 4, 2, 8, 8, apply_dither=True).close()   # float output: the flag is a no-op
+def test_dither_flag_is_a_no_op_on_float_output(orc, bfir):
+    """apply_dither only acts on integer formats (fftw_convolver.cpp:421, 444); see tests/test_dither_gpu.py."""
+    L, B, C, nb = 256, 2, 2, 5
+    rng = np.random.default_rng(1)
+    h = orc.synth_ir(rng, C, 400, np.float32); x = orc.synth_audio(rng, nb * L, C, np.float32)
+    a = bfir.Brutefir(L, B, 4, C, 8, 8, apply_dither=True); a.set_coeff(h)
+    b = bfir.Brutefir(L, B, 4, C, 8, 8, apply_dither=False); b.set_coeff(h)
+    assert np.array_equal(a.run(x)[1], b.run(x)[1])

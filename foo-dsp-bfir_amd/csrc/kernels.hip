@@ -837,7 +837,6 @@ __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB
     });
 }
 
-#define
 template <int PB, int D, bool ACC>
 __global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int ncol, int nR, int ngrp, int n_dc, int p0)
 {

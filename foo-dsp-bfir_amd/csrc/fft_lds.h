@@ -27,6 +27,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 // -DBFIR_TRACE (tuning builds only, scripts/gpu_trace.sh): thread 0 of every workgroup stamps the
 // 100 MHz wall clock at phase boundaries into a device array read back by bfir_debug_read_trace.
 #ifdef BFIR_TRACE
@@ -208,6 +210,27 @@ template <int SIGN, typename T> struct Dft<16, SIGN, T> {
     }
 };
 
+// compile-time loop: f(integral_constant<int, I>) for I = LO .. HI-1 (register arrays keep constant indices)
+template <int LO, int HI, typename Fn> __device__ __forceinline__ void static_for(Fn &&f)
+{
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
+// Twiddle bases.  A pass of radix R multiplies input r of a butterfly by w^{r k}.  Instead of fetching
+// all R-1 of them per transform, a PERSISTENT workgroup keeps w^{e k0} for a few exponents e in
+// registers for its whole life (k0 = tid mod min(p, NT) never changes) and forms the others as the
+// product of two of them: r = 4a + c -> w^{4a} w^{c} (radix 16: bases 1 2 3 4 8 12; radix 8: 1 2 3 4;
+// radix 4: 1 2, w^3 = w w^2).
+// One extra rounding per derived twiddle; no vector-memory traffic for twiddles in steady state.
+__host__ __device__ constexpr int tw_nbase(int R) { return R == 16 ? 6 : R == 8 ? 4 : R == 4 ? 2 : 1; }
+__host__ __device__ constexpr int tw_base_exp(int R, int j)
+{
+    return R == 16 ? (j < 4 ? j + 1 : 4 * (j - 2)) : j + 1;      // 16: 1 2 3 4 8 12; 8: 1 2 3 4; 4: 1 2; 2: 1
+}
+
 // ---- the workgroup transform ------------------------------------------------
 template <typename T, int LOG2M, int SIGN> struct LdsFft {
     using Cfg = FftCfg<LOG2M>;
@@ -242,23 +265,21 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
     // except the stride-R writes of the first pass (2-way).
 #ifdef BFIR_FFT_XOR_SWIZZLE   // A/B switch: conflict-free XOR layout, exactly M elements (5 workgroups per CU at M = 4096 fp32)
     static constexpr int LDS_ELEMS = M;
-    __device__ __forceinline__ static int phys(int i) { return i ^ ((i >> 4) & 15); }
+    __host__ __device__ __forceinline__ static constexpr int phys(int i) { return i ^ ((i >> 4) & 15); }
 #else
     static constexpr int LDS_ELEMS = M + M / 32;
-    __device__ __forceinline__ static int phys(int i) { return i + (i >> 5); }
+    __host__ __device__ __forceinline__ static constexpr int phys(int i) { return i + (i >> 5); }
 #endif
 
     // logical index held in register slot e before pass 0
-    __device__ __forceinline__ static int in_index(int tid, int e)
+    __host__ __device__ __forceinline__ static constexpr int in_index(int tid, int e)
     {
-        constexpr int R = radix(0);
-        return (tid + (e / R) * NT) + (e % R) * (M / R);
+        return (tid + (e / radix(0)) * NT) + (e % radix(0)) * (M / radix(0));
     }
     // logical index held in register slot e after the last pass
-    __device__ __forceinline__ static int out_index(int tid, int e)
+    __host__ __device__ __forceinline__ static constexpr int out_index(int tid, int e)
     {
-        constexpr int R = radix(NP - 1);
-        return (tid + (e / R) * NT) + Dft<R, SIGN, T>::inv(e % R) * (M / R);
+        return (tid + (e / radix(NP - 1)) * NT) + Dft<radix(NP - 1), SIGN, T>::inv(e % radix(NP - 1)) * (M / radix(NP - 1));
     }
 
     // twiddles of pass S for this thread: (P/R) butterflies x (R-1) factors
@@ -338,6 +359,91 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
         // the reads must not sink below the next barrier (see pin_registers)
 #pragma unroll
         for (int e = 0; e < P; e++) asm volatile("" : "+v"(re[e]), "+v"(im[e]));
+    }
+
+    // ---- twiddle bases: table layout, registers, derived twiddles -------------------------------
+    // table: for pass s >= 1, base j, k0 < kspan(s):  twb[boff(s) + j kspan(s) + k0] = exp(-2 pi i e_j k0 / (p R))
+    __host__ __device__ static constexpr int kspan(int s) { return pprod(s) < NT ? pprod(s) : NT; }
+    __host__ __device__ static constexpr int boff(int s)
+    {
+        int o = 0;
+        for (int j = 1; j < s; j++) o += tw_nbase(radix(j)) * kspan(j);
+        return o;
+    }
+    __host__ __device__ static constexpr int bsize() { return boff(NP); }
+    // Where a persistent workgroup keeps them: the bases of the LAST pass (k0 = tid, the big set) in
+    // NBREG registers per thread, those of the passes before it (k0 < 256: a few KB) in LDS, copied once.
+    static constexpr int NBREG = NP > 1 ? tw_nbase(radix(NP - 1)) : 1;
+    static constexpr int LDSB_ELEMS = NP > 2 ? boff(NP - 1) : 1;
+
+    // once per workgroup; a barrier must follow before the first butterflies_tb
+    __device__ __forceinline__ static void load_bases(V2 (&B)[NBREG], V2 *ldsb, const V2 *__restrict__ twb, int tid)
+    {
+        if constexpr (NP > 2)
+            for (int i = tid; i < LDSB_ELEMS; i += NT) ldsb[i] = twb[i];
+        if constexpr (NP > 1)
+            static_for<0, NBREG>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                B[J] = twb[boff(NP - 1) + J * kspan(NP - 1) + (tid & (kspan(NP - 1) - 1))];
+            });
+    }
+
+    template <int S, int J> __device__ __forceinline__ static V2 base(const V2 (&B)[NBREG], const V2 *ldsb, int tid)
+    {
+        if constexpr (S == NP - 1) return B[J];
+        else return ldsb[boff(S) + J * kspan(S) + (tid & (kspan(S) - 1))];
+    }
+
+    // w^{r k0} of pass S in the forward convention exp(-i theta): a base or the product of two
+    template <int S, int r> __device__ __forceinline__ static V2 base_twiddle(const V2 (&B)[NBREG], const V2 *ldsb, int tid)
+    {
+        constexpr int R = radix(S);
+        if constexpr (R == 16 && (r & 3) != 0 && (r >> 2) != 0) {
+            const V2 a = base<S, 2 + (r >> 2)>(B, ldsb, tid), c = base<S, (r & 3) - 1>(B, ldsb, tid);
+            V2 w; w.x = a.x * c.x - a.y * c.y; w.y = a.x * c.y + a.y * c.x;
+            return w;
+        } else if constexpr (R == 16) {
+            return base<S, ((r >> 2) == 0 ? r - 1 : 2 + (r >> 2))>(B, ldsb, tid);
+        } else if constexpr (R == 8 && r > 4) {
+            const V2 a = base<S, 3>(B, ldsb, tid), c = base<S, r - 5>(B, ldsb, tid);
+            V2 w; w.x = a.x * c.x - a.y * c.y; w.y = a.x * c.y + a.y * c.x;
+            return w;
+        } else if constexpr (R == 4 && r == 3) {
+            const V2 a = base<S, 0>(B, ldsb, tid), c = base<S, 1>(B, ldsb, tid);
+            V2 w; w.x = a.x * c.x - a.y * c.y; w.y = a.x * c.y + a.y * c.x;
+            return w;
+        } else {
+            return base<S, r - 1>(B, ldsb, tid);
+        }
+    }
+
+    // pass S (S >= 1) on register data with twiddles from the bases.  Butterfly b of a thread has
+    // k = (tid + b NT) mod p: the same k0 for every b when p <= NT, otherwise k0 + NT b' with
+    // b' = b mod (p / NT), i.e. a further constant rotation by w^{r NT b'} = exp(-2 pi i r b' / 16)
+    // (NT / (p R) = 1 / 16 whenever p > NT: such a pass is the last one and P = 16).
+    template <int S>
+    __device__ __forceinline__ static void butterflies_tb(T *re, T *im, const V2 (&B)[NBREG], const V2 *ldsb, int tid)
+    {
+        constexpr int R = radix(S), p = pprod(S);
+        static_assert(p <= NT || 16 * NT == p * R, "constant rotations are sixteenth roots of unity");
+        // one twiddle live at a time: derive w^{r k0}, apply it to input r of every butterfly, move on
+        static_for<1, R>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            // radix 16: four twiddles at a time.  Left alone the scheduler derives all fifteen first (30
+            // registers), which a persistent kernel with its prefetch registers cannot afford.
+            if constexpr (R == 16 && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const V2 w = base_twiddle<S, r>(B, ldsb, tid);
+            static_for<0, P / R>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                constexpr int bp = b % (p > NT ? p / NT : 1);            // 0 when p <= NT
+                cmul(re[b * R + r], im[b * R + r], w.x, (T)(SIGN < 0 ? w.y : -w.y));
+                if constexpr (bp != 0) mul_w16<(r * bp) % 16, SIGN>(re[b * R + r], im[b * R + r]);
+            });
+        });
+        static_for<0, P / R>([&](auto B_) {
+            constexpr int b = decltype(B_)::value;
+            Dft<R, SIGN, T>::run(re + b * R, im + b * R);
+        });
     }
 
     // Full transform of the P register points (in_index order in, out_index order out).

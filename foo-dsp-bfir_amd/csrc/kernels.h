@@ -37,6 +37,7 @@ struct FftPlan {
     int realsize = 0;     // 4 or 8
     void *tw = nullptr;   // per-pass twiddles  exp(-2 pi i r k / (p R))
     void *ws = nullptr;   // split twiddles     exp(-2 pi i k / N), k < M
+    void *twb = nullptr;  // twiddle bases of the persistent kernels (fft_lds.h)
 };
 
 int  fft_plan_create(FftPlan *plan, int filter_length, int realsize);   // 0 or negative error

@@ -47,6 +47,24 @@ template <int LOG2M> static void fill_tw(std::vector<long double> &tw)
     }
 }
 
+// twiddle bases of the persistent kernels (fft_lds.h): exp(-2 pi i e_j k0 / (p R)), k0 < min(p, NT)
+template <int LOG2M> static void fill_twb(std::vector<long double> &tw)
+{
+    using F = LdsFft<float, LOG2M, -1>;
+    tw.assign(2 * (size_t)(F::bsize() > 0 ? F::bsize() : 1), 0.0L);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int s = 1; s < F::NP; s++) {
+        const int R = F::radix(s), p = F::pprod(s), ks = F::kspan(s);
+        for (int j = 0; j < tw_nbase(R); j++)
+            for (int k0 = 0; k0 < ks; k0++) {
+                long double ang = -two_pi * (long double)(tw_base_exp(R, j) * k0) / (long double)(p * R);
+                size_t o = (size_t)F::boff(s) + (size_t)j * ks + k0;
+                tw[2 * o] = cosl(ang);
+                tw[2 * o + 1] = sinl(ang);
+            }
+    }
+}
+
 template <typename T> static void *upload(const std::vector<long double> &v)
 {
     std::vector<T> h(v.size());
@@ -78,9 +96,9 @@ int fft_plan_create(FftPlan *plan, int filter_length, int realsize)
     if (realsize != 4 && realsize != 8) return -1;
     // one transform's LDS buffer must fit: M complex values
     if (((size_t)filter_length + (size_t)filter_length / 32) * 2 * (size_t)realsize > 160 * 1024) return -1;
-    std::vector<long double> tw, ws;
+    std::vector<long double> tw, ws, twb;
     switch (lg) {
-#define F(lgv) case lgv: fill_tw<lgv>(tw); break;
+#define F(lgv) case lgv: fill_tw<lgv>(tw); fill_twb<lgv>(twb); break;
         BFIR_FOR_LOG2M(F)
 #undef F
     }
@@ -96,7 +114,8 @@ int fft_plan_create(FftPlan *plan, int filter_length, int realsize)
     plan->realsize = realsize;
     plan->tw = realsize == 4 ? upload<float>(tw) : upload<double>(tw);
     plan->ws = realsize == 4 ? upload<float>(ws) : upload<double>(ws);
-    if (!plan->tw || !plan->ws) { fft_plan_destroy(plan); return -2; }
+    plan->twb = realsize == 4 ? upload<float>(twb) : upload<double>(twb);
+    if (!plan->tw || !plan->ws || !plan->twb) { fft_plan_destroy(plan); return -2; }
     return 0;
 }
 
@@ -104,7 +123,8 @@ void fft_plan_destroy(FftPlan *plan)
 {
     if (plan->tw) (void)hipFree(plan->tw);
     if (plan->ws) (void)hipFree(plan->ws);
-    plan->tw = plan->ws = nullptr;
+    if (plan->twb) (void)hipFree(plan->twb);
+    plan->tw = plan->ws = plan->twb = nullptr;
 }
 
 // ---------------------------------------------------------------------------
@@ -777,14 +797,6 @@ template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
 // Bin 0 (DC | Nyquist, two independent real sums) is left to the first blocks
 // of the grid (one thread per channel and output block); the streaming lanes
 // never store it.
-// compile-time loop: f(integral_constant<int, I>) for I = LO .. HI-1 (register arrays keep constant indices)
-template <int LO, int HI, typename F> __device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (LO < HI) {
-        f(std::integral_constant<int, LO>{});
-        static_for<LO + 1, HI>(f);
-    }
-}
 
 // ACC (partition batches after the first, B > PB): the sums continue from the partial results the
 // previous batch left in Y; those are fetched D blocks ahead like the spectra (yq, ty_next).

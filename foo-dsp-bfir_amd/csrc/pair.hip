@@ -22,6 +22,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "fft_lds.h"
 
@@ -202,6 +203,393 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
     BFIR_STAMP(1, 11);
 }
 
+
+// ---- persistent forward kernel -------------------------------------------------------------------
+// What k_fwd_pair waits for is memory, not arithmetic (profiles/r02_alias_and_bottleneck_experiments.txt:
+// 0.235 ms of VALU + LDS under 0.33 ms of exposed load / store / twiddle time per 4096 blocks).
+// Here ONE workgroup transforms a run of consecutive blocks of one channel pair:
+//   * every block is loaded once: the half-window "current block" of transform t is the "previous
+//     block" of transform t+1 and stays in registers (same thread: n -> n - L keeps the lane);
+//   * the next block is fetched right after the first butterflies of the current transform and is
+//     only waited for when that transform has stored its spectra, which in turn drain while the
+//     next transform computes (a workgroup that ends with its stores keeps its CU slot until they land);
+//   * twiddles never touch memory in steady state: the bases of the last pass live in registers, those
+//     of the passes before it in 9 KB of LDS, for the workgroup's life (LdsFft::butterflies_tb), so
+//     nothing queues behind the prefetch in vmcnt order.
+// Same arithmetic as k_fwd_pair except that a derived twiddle carries one more rounding.
+// Buffer addressing for the persistent kernels: a wave-uniform descriptor (4 SGPRs) + one 32-bit lane
+// offset + a scalar offset per access, instead of a 64-bit address pair in VGPRs per access (the
+// one-transform kernels spend a quarter of their vector instructions and ~20 registers on those).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    // the pointer is workgroup-uniform by construction; readfirstlane tells the compiler so
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    float2 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y);
+    return f;
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 f)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 v; v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 f)
+{
+    u32x2 v; v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+// Prefetch loads the compiler must not wait for.  hipcc's s_waitcnt bookkeeping gives up at the head of
+// the transform loop ("vmcnt(0)": wait for everything, i.e. also for the spectrum stores of the previous
+// transform, which is exactly the overlap this kernel exists for).  So the in-loop prefetch is issued from
+// an asm statement (invisible to that bookkeeping) and waited for by hand with a counted vmcnt: vector
+// memory operations retire in issue order, so "all but the N youngest" with N = the stores issued after
+// the prefetch is precisely "the prefetch has landed".  (cdna_hip_programming.md 5.7 form (ii): "+v"
+// operands on load and wait statements pin the order; the .s is audited for copies in between.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_words(const void *p, unsigned bytes)
+{
+    const unsigned long long u = (unsigned long long)p;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));   // stride 0
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// 8 x 8 bytes per lane: d[e] <- buffer[voff + e * step]
+__device__ __forceinline__ void asm_prefetch8x2(u32x2 (&d)[8], unsigned voff, i32x4 r, unsigned step)
+{
+    const unsigned s1 = __builtin_amdgcn_readfirstlane(step), s2 = 2 * s1, s3 = 3 * s1, s4 = 4 * s1, s5 = 5 * s1, s6 = 6 * s1, s7 = 7 * s1;
+    asm volatile("s_nop 4\n\t"
+                 "buffer_load_dwordx2 %0, %8, %9, 0 offen\n\t"
+                 "buffer_load_dwordx2 %1, %8, %9, %10 offen\n\t"
+                 "buffer_load_dwordx2 %2, %8, %9, %11 offen\n\t"
+                 "buffer_load_dwordx2 %3, %8, %9, %12 offen\n\t"
+                 "buffer_load_dwordx2 %4, %8, %9, %13 offen\n\t"
+                 "buffer_load_dwordx2 %5, %8, %9, %14 offen\n\t"
+                 "buffer_load_dwordx2 %6, %8, %9, %15 offen\n\t"
+                 "buffer_load_dwordx2 %7, %8, %9, %16 offen"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+                 : "v"(voff), "s"(r), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)
+                 : "memory");
+}
+// 8 x 16 bytes per lane: a[j] <- buffer A[voff + j * step], b[j] <- buffer B[...]   (j < 4)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void asm_prefetch2x4x4(u32x4 (&a)[4], u32x4 (&b)[4], unsigned voff, i32x4 ra, i32x4 rb, unsigned step)
+{
+    const unsigned s1 = __builtin_amdgcn_readfirstlane(step), s2 = 2 * s1, s3 = 3 * s1;
+    asm volatile("s_nop 4\n\t"
+                 "buffer_load_dwordx4 %0, %8, %9, 0 offen\n\t"
+                 "buffer_load_dwordx4 %4, %8, %10, 0 offen\n\t"
+                 "buffer_load_dwordx4 %1, %8, %9, %11 offen\n\t"
+                 "buffer_load_dwordx4 %5, %8, %10, %11 offen\n\t"
+                 "buffer_load_dwordx4 %2, %8, %9, %12 offen\n\t"
+                 "buffer_load_dwordx4 %6, %8, %10, %12 offen\n\t"
+                 "buffer_load_dwordx4 %3, %8, %9, %13 offen\n\t"
+                 "buffer_load_dwordx4 %7, %8, %10, %13 offen"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "v"(voff), "s"(ra), "s"(rb), "s"(s1), "s"(s2), "s"(s3)
+                 : "memory");
+}
+// wait until all but the N youngest vector-memory operations of this wave are done; names the prefetch
+// destinations so that no use of them is scheduled above it
+template <int N, typename V, int K> __device__ __forceinline__ void asm_wait_vmcnt(V (&d)[K])
+{
+    static_assert(K == 8, "eight destinations");
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+                 : "n"(N) : "memory");
+}
+template <int N, typename V> __device__ __forceinline__ void asm_wait_vmcnt(V (&a)[4], V (&b)[4])
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N) : "memory");
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArgs a, const float2 *__restrict__ twb, int run_len)
+{
+    using F = LdsFft<float, LOG2N, -1>;
+    constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, H = P / 2;   // H points per thread and block
+    static_assert(F::radix(0) == 16 && P == 16, "in_index(tid, e) = tid + e * (N / 16)");
+    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) float2 ldsb[F::LDSB_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int w = xcd_remap();
+    const int half_c = a.C / 2, pairs = a.n_eng * half_c;
+    const int rr = w / pairs, pp = w - rr * pairs;                       // run, pair: the pairs of a run share an XCD
+    const int g = pp / half_c, cp = pp - g * half_c;
+    const int C = a.C;
+    const int t0 = rr * run_len, t1 = min(a.n_t, t0 + run_len);
+    if (t0 >= t1) return;
+
+    float2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);                                    // the first exchange's barrier publishes ldsb
+
+    // frame n = tid + e NT of a block of frames sits at byte  blk + 4 (e NT C + tid C)  (+ 8 cp for the pair)
+    const float *__restrict__ raw = a.raw + (long)g * a.eng_stride + a.frame_off * C + 2 * cp;
+    const long hist = (long)g * a.hist_eng_stride + 2 * cp;
+    const unsigned blk_bytes = (unsigned)L * C * 4u;
+    const unsigned fo = (unsigned)tid * (unsigned)C * 4u;                // lane offset into a block of frames
+    const unsigned estep = (unsigned)NT * C * 4u;                        // bytes between a thread's consecutive points
+    static_assert(H == 8, "the prefetch statement moves eight points per thread");
+    float2 cur[H];
+    u32x2 nxt[H];                                                        // raw frames of the next block, as loaded
+    {
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((t0 == 0) ? a.prev + hist : raw + (long)(t0 - 1) * L * C, blk_bytes);
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const float2 v = buf_load2(ro, fo, e * estep);
+            cur[e].x = v.x * a.scale; cur[e].y = v.y * a.scale;
+        }
+        if (a.n_t == 1) {                                                // one-block chunk: the other history block moves on unchanged
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.carry + hist, blk_bytes), rp = make_rsrc(a.save_prev + hist, blk_bytes);
+#pragma unroll
+            for (int e = 0; e < H; e++) buf_store2(rp, fo, e * estep, buf_load2(rc, fo, e * estep));
+        }
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(raw + (long)t0 * L * C, blk_bytes);
+#pragma unroll
+        for (int e = 0; e < H; e++) nxt[e] = __builtin_amdgcn_raw_buffer_load_b64(rb, fo, e * estep, 0);
+        // these (compiler-counted) loads are consumed before the loop, so inside it the compiler has no
+        // pending load of its own to wait for
+#pragma unroll
+        for (int e = 0; e < H; e++) asm volatile("" : "+v"(nxt[e]));
+    }
+    float *__restrict__ da0 = a.dst + (long)(g * C + 2 * cp) * a.dst_ch_stride;
+    for (int t = t0; t < t1; t++) {
+        float re[P], im[P];
+        // block t has landed when all but the 2 (P/4) spectrum stores issued after its prefetch are done
+        asm_wait_vmcnt<2 * (P / 4)>(nxt);
+        if (t >= a.n_t - 2) {                                            // uniform: the chunk's last two blocks
+            // the engine's history: raw frames of the last two blocks of the chunk (stores only: nothing in
+            // this branch for the compiler to wait for, and it lies outside the window the counted wait spans)
+            const __amdgpu_buffer_rsrc_t rk = make_rsrc((t == a.n_t - 1 ? a.save_last : a.save_prev) + hist, blk_bytes);
+#pragma unroll
+            for (int e = 0; e < H; e++) __builtin_amdgcn_raw_buffer_store_b64(nxt[e], rk, fo, e * estep, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            float2 v; v.x = __uint_as_float(nxt[e].x); v.y = __uint_as_float(nxt[e].y);   // raw frames of block t
+            re[e] = cur[e].x; im[e] = cur[e].y;                          // window = [block t-1 | block t]
+            cur[e].x = v.x * a.scale; cur[e].y = v.y * a.scale;
+            re[H + e] = cur[e].x; im[H + e] = cur[e].y;
+        }
+        {
+            float2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            // LDS addresses are formed afresh per phase from an opaque copy of the lane index: otherwise
+            // the compiler hoists a dozen of them out of the transform loop and spills them around it
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+            if constexpr (S == 1) {
+                // fetch block t+1 under the remaining passes (after the widest butterfly); past the end of
+                // the run the descriptor has zero bytes and the loads return zeros (no branch, see above)
+                asm_prefetch8x2(nxt, fo, make_rsrc_words(raw + (long)(t + 1) * L * C, t + 1 < t1 ? blk_bytes : 0u), estep);
+            }
+        });
+
+        // Z in natural order to LDS, then two-for-one split
+        int tz = tid; asm volatile("" : "+v"(tz));
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            float2 v; v.x = re[e]; v.y = im[e];
+            lds[F::phys(F::out_index(tz, e))] = v;
+        }
+        __syncthreads();
+        const long slot = (long)((a.base_slot + t) % a.ring) * N;
+        const __amdgpu_buffer_rsrc_t rxa = make_rsrc(da0 + slot, (unsigned)N * 4u), rxb = make_rsrc(da0 + a.dst_ch_stride + slot, (unsigned)N * 4u);
+        // A thread splits two ADJACENT bins (k = 2 m, 2 m + 1; m = tid + j NT) so that each spectrum store is
+        // 16 bytes per lane: vector stores are issue-bound per instruction on this chip (8-byte stores run at
+        // about 7 B/clk/CU, MI355X_MICROARCH.md cycle table), and this kernel stores twice what it loads.
+#pragma unroll
+        for (int j = 0; j < P / 4; j++) {
+            // one pair at a time: left alone the scheduler fetches all sixteen Z values first (32 registers
+            // on top of the prefetch and the carried block)
+            if (j > 0) __builtin_amdgcn_sched_barrier(0);
+            const int m = tz + j * NT, k = 2 * m;
+            const float2 zk0 = lds[F::phys(k)], zk1 = lds[F::phys(k + 1)];
+            const float2 zn0 = lds[F::phys((N - k) & (N - 1))], zn1 = lds[F::phys(N - k - 1)];
+            float4 xa, xb;
+            xa.x = 0.5f * (zk0.x + zn0.x); xa.y = 0.5f * (zk0.y - zn0.y);
+            xb.x = 0.5f * (zk0.y + zn0.y); xb.y = -0.5f * (zk0.x - zn0.x);
+            xa.z = 0.5f * (zk1.x + zn1.x); xa.w = 0.5f * (zk1.y - zn1.y);
+            xb.z = 0.5f * (zk1.y + zn1.y); xb.w = -0.5f * (zk1.x - zn1.x);
+            if (j == 0) {                                                // m = tid: bin 0 is DC | Nyquist, both real
+                const float2 zh = lds[F::phys(L)];
+                const bool k0 = tz == 0;
+                xa.x = k0 ? zk0.x : xa.x; xa.y = k0 ? zh.x : xa.y; xb.x = k0 ? zk0.y : xb.x; xb.y = k0 ? zh.y : xb.y;
+            }
+            buf_store4(rxa, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xa);
+            buf_store4(rxb, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xb);
+        }
+        // the next transform's first exchange starts with a barrier, which also protects these LDS reads
+    }
+}
+
+// ---- persistent inverse kernel ---------------------------------------------------------------------
+// The same treatment for the way back: one workgroup turns a run of consecutive product spectra of one
+// channel pair into output frames.  The next block's two spectra (64 KiB per workgroup) are fetched into
+// registers (8 x 16 bytes per thread) under the passes of the current transform and only staged into LDS
+// when the passes are done with it; the 8-byte strided output stores drain under the next transform;
+// twiddles from bases (LdsFft::butterflies_tb); overflow statistics reduced once per run, not per block.
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    float4 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArgs a, const float2 *__restrict__ twb, int run_len)
+{
+    using F = LdsFft<float, LOG2N, +1>;
+    constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, Q = P / 4;   // Q 16-byte pieces per thread and spectrum
+    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) float2 ldsb[F::LDSB_ELEMS];
+    __shared__ unsigned int red_max[NT / 64 > 0 ? NT / 64 : 1][2], red_cnt[NT / 64 > 0 ? NT / 64 : 1][2];
+
+    const int tid = threadIdx.x;
+    const int w = xcd_remap();
+    const int half_c = a.C / 2, pairs = a.n_eng * half_c;
+    const int rr = w / pairs, pp = w - rr * pairs;
+    const int g = pp / half_c, cp = pp - g * half_c;
+    const int C = a.C;
+    const int gc = g * C + 2 * cp;
+    const int t0 = rr * run_len, t1 = min(a.n_t, t0 + run_len);
+    if (t0 >= t1) return;
+
+    float2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);
+
+    const float *__restrict__ ya0 = a.y + (long)gc * a.y_ch_stride;
+    float *__restrict__ out0 = a.raw + (long)g * a.eng_stride + a.frame_off * C + 2 * cp;
+    const unsigned blk_bytes = (unsigned)L * C * 4u;
+    static_assert(Q == 4, "the prefetch statement moves four 16-byte pieces per thread and spectrum");
+    u32x4 qa[Q], qb[Q];
+    {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(ya0 + (long)t0 * N, (unsigned)N * 4u);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(ya0 + a.y_ch_stride + (long)t0 * N, (unsigned)N * 4u);
+#pragma unroll
+        for (int j = 0; j < Q; j++) {
+            qa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, 0);
+            qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, 0);
+        }
+        // consumed before the loop: inside it the compiler has no pending load of its own (see k_fwd_pair_ps)
+#pragma unroll
+        for (int j = 0; j < Q; j++) asm volatile("" : "+v"(qa[j]), "+v"(qb[j]));
+    }
+    const float rmax = a.max, rmin = -a.max;
+    unsigned int mx0 = 0u, mx1 = 0u, c0 = 0u, c1 = 0u;
+    int bad = 0x7fffffff;
+    for (int t = t0; t < t1; t++) {
+        // both spectra into LDS: Ya at [0, L), Yb at [L, 2L)  (float2 units)
+        int ts = tid; asm volatile("" : "+v"(ts));
+        // block t's spectra have landed when all but the P/2 output stores issued after their prefetch are done
+        asm_wait_vmcnt<P / 2>(qa, qb);
+        __syncthreads();                                                 // the previous transform's readers are done
+        {
+            u32x4 *l4 = (u32x4 *)lds;
+#pragma unroll
+            for (int j = 0; j < Q; j++) { l4[ts + j * NT] = qa[j]; l4[L / 2 + ts + j * NT] = qb[j]; }
+        }
+        __syncthreads();
+        // Z[k] = Ya[k] + i Yb[k], Hermitian-extended to the full circle
+        float re[P], im[P];
+        static_for<0, P>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            // k = base + tid with a compile-time base: which side of L a point lies on is known per e,
+            // and only e with base 0 / base L can hit the two real bins (tid 0) -- selects, no branches
+            constexpr int base = F::in_index(0, e);
+            static_assert(base + NT <= L || base >= L, "a thread's points do not straddle L");
+            const int k = base + ts;
+            const int kk = (base < L) ? k : N - k;                       // kk == L only for base == L, tid == 0
+            const bool edge = (base == 0 || base == L) && ts == 0;
+            const float2 pa = lds[edge ? 0 : kk], pb = lds[L + (edge ? 0 : kk)];
+            float zr, zi;
+            if (base < L) { zr = pa.x - pb.y; zi = pa.y + pb.x; }
+            else          { zr = pa.x + pb.y; zi = pb.x - pa.y; }         // conj Ya + i conj Yb
+            if (base == 0) { zr = edge ? pa.x : zr; zi = edge ? pb.x : zi; }   // DC of both channels
+            if (base == L) { zr = edge ? pa.y : zr; zi = edge ? pb.y : zi; }   // Nyquist of both channels
+            re[e] = zr * a.scale; im[e] = zi * a.scale;
+        });
+        pin_registers(re, im);   // every read of the staged spectra happens before the first exchange's barrier
+        {
+            float2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+            if constexpr (S == 1) {
+                // the next block's spectra, under the remaining passes; past the end of the run the descriptors
+                // have zero bytes and the loads return zeros (no branch in the loop, see k_fwd_pair_ps)
+                const unsigned nbytes = t + 1 < t1 ? (unsigned)N * 4u : 0u;
+                asm_prefetch2x4x4(qa, qb, (unsigned)tl * 16u, make_rsrc_words(ya0 + (long)(t + 1) * N, nbytes),
+                                  make_rsrc_words(ya0 + a.y_ch_stride + (long)(t + 1) * N, nbytes), (unsigned)NT * 16u);
+            }
+        });
+
+        // first L samples are the valid half (the taps sit in the upper half of their blocks)
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(out0 + (long)t * L * C, blk_bytes);
+        int to = tid; asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int n = F::out_index(to, e);
+            if (F::out_index(0, e) < L) {                                // compile time: out_index(tid, e) = tid + const, tid < NT <= L
+                float2 v; v.x = re[e]; v.y = im[e];
+                buf_store2(ro, (unsigned)to * (unsigned)C * 4u, (unsigned)F::out_index(0, e) * (unsigned)C * 4u, v);
+                // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+                c0 += ((v.x < 0.f) ? (v.x < rmin) : (v.x > rmax)) ? 1u : 0u;
+                c1 += ((v.y < 0.f) ? (v.y < rmin) : (v.y > rmax)) ? 1u : 0u;
+                const unsigned int b0 = (v.x == v.x) ? __float_as_uint(fabsf(v.x)) : 0u;
+                const unsigned int b1 = (v.y == v.y) ? __float_as_uint(fabsf(v.y)) : 0u;
+                mx0 = b0 > mx0 ? b0 : mx0; mx1 = b1 > mx1 ? b1 : mx1;
+                // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked; the first bad block
+                // of the run is reported once, after the loop (no atomic inside it)
+                if (F::out_index(0, e) == 0) {
+                    const bool nf = n == 0 && !(isfinite(v.x) && isfinite(v.y));
+                    bad = (nf && t < bad) ? t : bad;
+                }
+            }
+        }
+    }
+    if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int m0 = __shfl_xor(mx0, o), m1 = __shfl_xor(mx1, o);
+        mx0 = m0 > mx0 ? m0 : mx0; mx1 = m1 > mx1 ? m1 : mx1;
+        c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o);
+    }
+    if ((tid & 63) == 0) { red_max[tid >> 6][0] = mx0; red_max[tid >> 6][1] = mx1; red_cnt[tid >> 6][0] = c0; red_cnt[tid >> 6][1] = c1; }
+    __syncthreads();
+    if (tid < 2) {
+        unsigned int m = 0u, n = 0u;
+        for (int wv = 0; wv < (NT + 63) / 64; wv++) { m = red_max[wv][tid] > m ? red_max[wv][tid] : m; n += red_cnt[wv][tid]; }
+        DevOverflow *of = a.overflow + (gc + tid);
+        if (n) atomicAdd(&of->n_overflows, n);
+        // filtered: the peak only ever grows, a stale read costs an extra atomic, never a wrong result
+        if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
+            atomicMax(&of->largest_bits, (unsigned long long)m);
+    }
+}
+
 }  // namespace
 
 #define BFIR_FOR_PAIR_LOG2N(F) F(10) F(11) F(12) F(13) F(14)
@@ -211,10 +599,36 @@ bool pair_supported(int filter_length)
     return filter_length >= 512 && filter_length <= 8192;             // N = 2L complex points, 2^10 .. 2^14 (whole waves)
 }
 
+// Blocks per workgroup of the persistent kernels.  Long runs are best for a kernel on its own (forward:
+// 16 blocks) but the engine runs forward, MAC and inverse of neighbouring chunks concurrently, and a
+// kernel made of a few hundred long-lived workgroups holds every CU slot until it ends, so the other
+// two cannot slip in: the pipeline is fastest with SHORT runs (profiles/r02_pair_run_sweep.txt:
+// 108 Gsamples/s at 4 blocks per workgroup against 95 at 32).  BFIR_PAIR_RUN_FWD / _INV override (tuning aid);
+// BFIR_PAIR_PERSIST=0 keeps the one-transform-per-workgroup kernels.
+static int pair_run_len(int n_t, int pairs, bool inverse)
+{
+    if (const char *e = getenv(inverse ? "BFIR_PAIR_RUN_INV" : "BFIR_PAIR_RUN_FWD")) return std::max(1, atoi(e));
+    const int slots = 512;                                 // 256 CUs x 2 workgroups
+    const int runs = std::max(1, slots / std::max(1, pairs));
+    const int fill = std::max(1, (n_t + runs - 1) / runs); // what one round of workgroups would need
+    return std::min(fill, 4);
+}
+
 void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a, hipStream_t s)
 {
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
+    const char *pe = getenv("BFIR_PAIR_PERSIST");
+    if (!(pe && atoi(pe) == 0) && plan.twb) {
+        const int pairs = a.n_eng * (a.C / 2);
+        const int len = pair_run_len(a.n_t, pairs, false), runs = (a.n_t + len - 1) / len;
+        switch (plan.log2m) {
+#define F(lg) case lg: hipLaunchKernelGGL((k_fwd_pair_ps<lg>), dim3(runs * pairs), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.twb, len); break;
+            BFIR_FOR_PAIR_LOG2N(F)
+#undef F
+        }
+        return;
+    }
     switch (plan.log2m) {
 #define F(lg) case lg: hipLaunchKernelGGL((k_fwd_pair<lg>), dim3(items), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.tw); break;
         BFIR_FOR_PAIR_LOG2N(F)
@@ -226,6 +640,17 @@ void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a, hipStream_t s)
 {
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
+    const char *pe = getenv("BFIR_PAIR_PERSIST");
+    if (!(pe && (atoi(pe) == 0 || atoi(pe) == 2)) && plan.twb) {        // 2: persistent forward kernel only (A/B)
+        const int pairs = a.n_eng * (a.C / 2);
+        const int len = pair_run_len(a.n_t, pairs, true), runs = (a.n_t + len - 1) / len;
+        switch (plan.log2m) {
+#define F(lg) case lg: hipLaunchKernelGGL((k_inv_pair_ps<lg>), dim3(runs * pairs), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.twb, len); break;
+            BFIR_FOR_PAIR_LOG2N(F)
+#undef F
+        }
+        return;
+    }
     switch (plan.log2m) {
 #define F(lg) case lg: hipLaunchKernelGGL((k_inv_pair<lg>), dim3(items), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.tw); break;
         BFIR_FOR_PAIR_LOG2N(F)

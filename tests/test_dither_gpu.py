@@ -131,7 +131,8 @@ def test_engine_with_dither_bit_exact(orc, bfir, s, fmt, C, chunk):
     assert sum(ed.overflow(c).n_overflows for c in range(C)) > 0
     # dither is not plain requantisation
     en = bfir.Brutefir(L, B, s, C, in_fmt, fmt, sampling_rate=srate); en.set_chunk(chunk); en.set_coeff(h, scale=gain)
-    assert (orc.decode_ints(en.run(x)[1], fmt) != orc.decode_ints(yd, fmt)).mean() > 0.2
+    if not (s == 4 and orc.FMT_BYTES[fmt] == 4):             # a +-1 LSB dither vanishes in fp32 next to 2^30 (also in the reference)
+        assert (orc.decode_ints(en.run(x)[1], fmt) != orc.decode_ints(yd, fmt)).mean() > 0.2
     # reset() touches counters only (brutefir.cpp:346-367): table position and error feedback carry on
     ed.reset(); ef.reset(); od.reset_counters()
     _, yd2 = ed.run(x[:4 * L]); _, yf2 = ef.run(x[:4 * L])

@@ -134,6 +134,11 @@ struct bfir_engine {
     // (every engine of a batch would build the same one) and dither_state_t per global channel
     int8_t *d_dither_tab = nullptr; int dither_size = 0;
     DevDitherState *d_dither_state = nullptr;
+    // latency path (bfir_engine_run with a handful of blocks, the plug-in's one run() per block): everything
+    // on one stream, no events, kernels read and write the pinned staging buffers across the host link
+    bool inline_launch = false;            // set around run_chunk by run_small()
+    bool async_pending = false;            // run_device queued work that nobody has waited for yet
+    int *h_bad = nullptr;                  // pinned copy of d_bad
     bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
@@ -182,6 +187,7 @@ static void free_work(bfir_engine *e)
     }
     e->stage_bytes_in = e->stage_bytes_out = 0;
     e->chunk = e->ring = 0;
+    if (e->h_bad) { (void)hipHostFree(e->h_bad); e->h_bad = nullptr; }
 }
 
 // (Re)allocate the chunk-sized work buffers.  The delay line is carried over
@@ -548,10 +554,11 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
     }
     const int par = (int)(e->chunk_seq & 1);
     const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
-    hipStream_t sf = e->serial ? st : e->s_front;
-    hipStream_t sm = e->pipe3 ? e->s_mac : st;
+    const bool il = e->inline_launch;                                     // one stream, stream order is the only order
+    hipStream_t sf = (e->serial || il) ? st : e->s_front;
+    hipStream_t sm = (e->pipe3 && !il) ? e->s_mac : st;
     if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
-    if (e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
+    if (!il && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
     // input_timecbuf bookkeeping as in run_chunk: block j of the chunk lands in buffer !(curbuf ^ (j & 1))
     const int idx_last = 1 ^ e->curbuf ^ ((tc - 1) & 1);
     {
@@ -568,9 +575,11 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         launch_fwd_pair(e->plan2, a, sf);
     }
     e->hist_raw[0] = e->tails[par][0]; e->hist_raw[1] = e->tails[par][1];
-    HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
-    HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
-    if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
+        HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
+        if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    }
     void *Y = e->Yb[e->pipe3 ? par : 0];
     {
         ProfScope ps(e, BFIR_K_MAC, sm);
@@ -583,8 +592,10 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.interleaved = 1;
         launch_mac(a, sm);
     }
-    HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
-    if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
+        if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    }
     {
         ProfScope ps(e, BFIR_K_INV, st);
         InvPairArgs a;
@@ -595,7 +606,7 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
         launch_inv_pair(e->plan2, a, st);
     }
-    if (e->pipe3) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
+    if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
     e->curbuf ^= (tc & 1);
     e->blockcounter += (unsigned long long)tc;
     e->chunk_seq += 1;
@@ -610,7 +621,8 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
     const long t_stride = (long)e->chunk * e->L;
     void *tin = e->tin[par];
     const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
-    hipStream_t sf = e->serial ? st : e->s_front;
+    const bool il = e->inline_launch;                                     // one stream, stream order is the only order
+    hipStream_t sf = (e->serial || il) ? st : e->s_front;
 
     // the front only waits for the input, never for the back of the chunk before
     if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
@@ -624,7 +636,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.realsize = e->s;
         launch_stage_in(a, sf);
     }
-    if (e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
+    if (!il && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
     {
         ProfScope ps(e, BFIR_K_FWD, sf);
         FwdArgs a;
@@ -640,10 +652,12 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.interleaved = e->ilv;
         launch_fwd(e->plan, a, sf);
     }
-    HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
-    hipStream_t sm = e->pipe3 ? e->s_mac : st;
-    HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
-    if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    hipStream_t sm = (e->pipe3 && !il) ? e->s_mac : st;
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
+        HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
+        if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    }
     void *Y = e->Yb[e->pipe3 ? par : 0];
     {
         ProfScope ps(e, BFIR_K_MAC, sm);
@@ -656,8 +670,10 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.interleaved = e->ilv;
         launch_mac(a, sm);
     }
-    HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
-    if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
+        if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    }
     {
         ProfScope ps(e, BFIR_K_INV, st);
         InvArgs a;
@@ -669,7 +685,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.interleaved = e->ilv;
         launch_inv(e->plan, a, st);
     }
-    if (e->pipe3) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
+    if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
     {
         ProfScope ps(e, BFIR_K_STAGE_OUT, st);
         StageOutArgs a;
@@ -729,6 +745,7 @@ extern "C" int bfir_engine_run_device(bfir_engine *e, const void *d_in, long in_
         if (rc != BFIR_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
+    e->async_pending = true;
     return BFIR_OK;
 }
 
@@ -737,6 +754,7 @@ extern "C" int bfir_engine_sync(bfir_engine *e)
     if (!e) return BFIR_ERR_ARG;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    e->async_pending = false;
     drain_spans(e);
     int bad = INT_MAX;
     HIP_TRY(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
@@ -770,9 +788,9 @@ static void copy_host(void *dst, const void *src, size_t n)
 // Host-path chunk: the link, not the GPU, bounds this path, so the pinned staging buffers stay small.
 static int host_chunk(const bfir_engine *e) { return std::min(e->chunk, 512); }
 
-static int ensure_staging(bfir_engine *e)
+static int ensure_staging(bfir_engine *e, int min_blocks = 0)
 {
-    const int hc = host_chunk(e);
+    const int hc = std::max(host_chunk(e), min_blocks);
     const size_t bin = (size_t)e->n_eng * hc * e->L * e->C * e->in_bytes;
     const size_t bout = (size_t)e->n_eng * hc * e->L * e->C * e->out_bytes;
     if (e->stage_bytes_in >= bin && e->stage_bytes_out >= bout) return BFIR_OK;
@@ -791,6 +809,40 @@ static int ensure_staging(bfir_engine *e)
     return BFIR_OK;
 }
 
+// A handful of blocks per call -- the plug-in's pattern is ONE (foo_dsp_bfir.cpp:311-349): what
+// counts is the latency of the call, not throughput.  No copy engine, no second stream, no event: the
+// caller's frames go into the pinned staging buffer, the kernels read them from there and write the output
+// frames into the other one straight across the host link (a block is a few KiB), launched back to back on
+// one stream; one 4-byte copy brings the NaN verdict; one stream synchronise ends the call.
+static constexpr int kSmallRun = 4;
+static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_blocks)
+{
+    int rc = ensure_chunk(e, n_blocks);
+    if (rc != BFIR_OK) return rc;
+    rc = ensure_staging(e, kSmallRun);
+    if (rc != BFIR_OK) return rc;
+    if (e->async_pending) { HIP_TRY(hipDeviceSynchronize()); e->async_pending = false; }
+    if (!e->h_bad) { HIP_TRY(hipHostMalloc((void **)&e->h_bad, sizeof(int), hipHostMallocDefault)); }
+    const size_t per_in = (size_t)n_blocks * e->L * e->C * e->in_bytes, per_out = (size_t)n_blocks * e->L * e->C * e->out_bytes;
+    memcpy(e->pin_in[0], inbuf, per_in * e->n_eng);       // engine after engine, n_blocks * L frames each: same layout
+    e->inline_launch = true;
+    for (int c0 = 0; c0 < n_blocks && rc == BFIR_OK; c0 += e->chunk)       // the work buffers hold e->chunk blocks
+        rc = run_chunk(e, e->pin_in[0], (long)per_in, e->pin_out[0], (long)per_out, (long)c0 * e->L,
+                       std::min(e->chunk, n_blocks - c0), c0, e->stream, nullptr);
+    e->inline_launch = false;
+    if (rc != BFIR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    drain_spans(e);
+    memcpy(outbuf, e->pin_out[0], per_out * e->n_eng);
+    if (*e->h_bad != 0x7f7f7f7f) {
+        HIP_TRY(hipMemset(e->d_bad, 0x7f, sizeof(int)));
+        bfir_logf("NaN or Inf values in the system! Invalid input? Aborting.\n");
+        return BFIR_ERR_NONFINITE;
+    }
+    return BFIR_OK;
+}
+
 // Host-pointer run: pinned double buffers, H2D on s_in, kernels on the engine's
 // streams, D2H on s_out, so the copies of neighbouring chunks overlap the compute
 // (the reference's raw2real / real2raw staging, fftw_convolver.cpp:156-185, 405-466,
@@ -801,6 +853,7 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
     if (!bfir_engine_is_initialized(e)) return BFIR_ERR_STATE;
     if (n_blocks == 0) return BFIR_OK;
     HIP_TRY(hipSetDevice(e->device));
+    if (n_blocks <= kSmallRun && !getenv("BFIR_NO_SMALL_RUN")) return run_small(e, inbuf, outbuf, n_blocks);
     int rc = ensure_chunk(e, std::min(n_blocks, 512));   // see host_chunk()
     if (rc != BFIR_OK) return rc;
     rc = ensure_staging(e);
@@ -849,7 +902,13 @@ extern "C" void bfir_engine_reset(bfir_engine *e)
     // input_timecbuf halves are kept (copied out of the work buffers).
     (void)materialise_history(e);
     (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
-    (void)hipMemset(e->X, 0, (size_t)e->GC * e->ring * cbuf_bytes(e));
+    // block t < B-1 of the new run still reads slots (t - i) mod ring, i > t: the B-1 slots at the top of
+    // every channel's ring.  Only those need to read as zero; the rest is rewritten before it is read.
+    if (e->B > 1) {
+        const size_t cb = cbuf_bytes(e);
+        (void)hipMemset2D((char *)e->X + (size_t)(e->ring - (e->B - 1)) * cb, (size_t)e->ring * cb, 0,
+                          (size_t)(e->B - 1) * cb, (size_t)e->GC);
+    }
     (void)hipDeviceSynchronize();
     e->blockcounter = 0;
     e->curbuf = 0;

@@ -768,6 +768,138 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds_d(MacArgs a, int nbt, int nT
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_mac_lds_d2: the fp64 LDS MAC with TWO bins per lane and EIGHT blocks per wave
+// ---------------------------------------------------------------------------
+// k_mac_lds_d reads 128 bytes of LDS per lane and step (H_i and one delay-line spectrum, 4 bins each) for
+// 64 double FMAs; eight waves per CU doing that need the whole 256 B/clk of the LDS, which is what bounds it
+// (a wave64 DFMA issues every 4 cycles).  With half a group per lane (2 bins: 16 bytes of real parts + 16 of
+// imaginary parts per spectrum) the same registers hold 8 output blocks instead of 4, so a step is still 64
+// FMAs per lane but on 64 bytes of LDS.  The data movement is then byte for byte that of the fp32 kernel
+// k_mac_lds (16-byte planes, 32-entry ring, 32-block time tiles, duty waves 0/1 fetch H re/im, 2/3 fetch
+// X[tb - s] re/im); lanes 2g and 2g+1 share group g of the grouped layout.  Same fma chain per bin and the
+// same partition order as every other MAC kernel: bit-identical sums.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cmac2d(v2d &ar, v2d &ai, const v2d &xr, const v2d &xi, const v2d &hr, const v2d &hi)
+{
+    ar = __builtin_elementwise_fma(xr, hr, ar); ar = __builtin_elementwise_fma(-xi, hi, ar);
+    ai = __builtin_elementwise_fma(xr, hi, ai); ai = __builtin_elementwise_fma(xi, hr, ai);
+}
+
+template <int D, bool DCNY>
+__device__ __forceinline__ void mac_lds_steps_d2(v2d (&accr)[8], v2d (&acci)[8], double (&dc)[8], double (&ny)[8],
+                                                 v2d (&wr)[8], v2d (&wi)[8], v2d (*s_ring)[2][64], v2d (*s_h)[2][64],
+                                                 const v2d *__restrict__ dbase, long duty_slot, bool duty_is_h,
+                                                 int nb, int ring, int sl_tb, int lane, int wv, int duty_plane)
+{
+    // duty: this wave fetches one plane (re or im; dbase already points at it) of H_s (waves 0, 1) or of
+    // X[tb - s] (waves 2, 3) for every step s, D steps ahead of its use
+    v2d q[D];
+    int dnext = duty_is_h ? 0 : sl_tb;
+#define BFIR_DUTY_ADVANCE()                                                                         \
+    do {                                                                                            \
+        if (duty_is_h) { if (dnext < nb - 1) dnext += 1; }                                          \
+        else { dnext -= 1; if (dnext < 0) dnext += ring; }                                          \
+    } while (0)
+#define BFIR_DUTY_LOAD() dbase[dnext * duty_slot]
+#define BFIR_DUTY_STORE(s_, v_)                                                                     \
+    do {                                                                                            \
+        v2d *dst_ = duty_is_h ? &s_h[(s_) & 1][duty_plane][lane] : &s_ring[(-(s_)) & 31][duty_plane][lane]; \
+        *dst_ = (v_);                                                                               \
+    } while (0)
+    if (duty_is_h) { const v2d h0 = BFIR_DUTY_LOAD(); BFIR_DUTY_STORE(0, h0); }
+#pragma unroll
+    for (int d = 0; d < D; d++) { BFIR_DUTY_ADVANCE(); q[(1 + d) % D] = BFIR_DUTY_LOAD(); }   // steps 1 .. D
+    __syncthreads();
+    for (int i0 = 0; i0 < nb; i0 += 8) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            const int i = i0 + ii;
+            if (i < nb) {   // uniform over the workgroup
+                const v2d hr = s_h[ii & 1][0][lane], hi = s_h[ii & 1][1][lane];
+                if (i > 0) {
+                    const int e = (8 * wv - i) & 31;             // ring entry holding X[tb + 8 wv - i]
+                    wr[(8 - ii) % 8] = s_ring[e][0][lane]; wi[(8 - ii) % 8] = s_ring[e][1][lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int idx = (j - ii + 8) % 8;            // window slot holding X[t0 + j - i]
+                    cmac2d(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                    if constexpr (DCNY) {
+                        dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                        ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                    }
+                }
+                // publish the operands of step i+1, refill the queue slot with those of step i+1+D
+                BFIR_DUTY_STORE(i + 1, q[(ii + 1) % D]);
+                BFIR_DUTY_ADVANCE();
+                q[(ii + 1) % D] = BFIR_DUTY_LOAD();
+                __syncthreads();
+            }
+        }
+    }
+#undef BFIR_DUTY_ADVANCE
+#undef BFIR_DUTY_LOAD
+#undef BFIR_DUTY_STORE
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_mac_lds_d2(MacArgs a, int nbt, int nTQ)
+{
+    __shared__ __attribute__((aligned(16))) v2d s_ring[32][2][64];
+    __shared__ __attribute__((aligned(16))) v2d s_h[2][2][64];
+    static_assert(8 % D == 0, "prefetch depth must divide the unroll");
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTQ, tq = w - s * nTQ;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = bt * 32 + (lane >> 1), hh = lane & 1;              // group of 4 bins, which half of it
+    const int tb = tq * 32, t0 = tb + 8 * wv;
+    const long slot = a.N / 2;                                        // v2d elements per spectrum
+    // grouped layout: group g = doubles 8g .. 8g+7 = re0 re1 | re2 re3 | im0 im1 | im2 im3 as four v2d
+    const v2d *__restrict__ X = (const v2d *)((const double *)a.x + (long)gc * a.x_ch_stride) + 4 * g + hh;
+    const v2d *__restrict__ H = (const v2d *)((const double *)a.h + (long)gc * a.h_ch_stride) + 4 * g + hh;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+    const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
+    v2d accr[8], acci[8], wr[8], wi[8];
+    double dc[8], ny[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        accr[j] = v2d{0, 0}; acci[j] = v2d{0, 0};
+        dc[j] = 0.0; ny[j] = 0.0;
+        int sj = sl_tb + 8 * wv + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot]; wi[j] = X[sj * slot + 2];
+        s_ring[8 * wv + j][0][lane] = wr[j]; s_ring[8 * wv + j][1][lane] = wi[j];
+    }
+    const bool duty_is_h = wv < 2;
+    const int plane = wv & 1;
+    const v2d *dbase = (duty_is_h ? H : X) + 2 * plane;
+    if (bt == 0)   // lane 0 of this tile holds bin 0: DC in the real slot, Nyquist in the imaginary one
+        mac_lds_steps_d2<D, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+    else
+        mac_lds_steps_d2<D, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+    double *__restrict__ Y = (double *)a.y + (long)gc * a.y_ch_stride;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) {
+            if (g == 0 && hh == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            v2d *yo = (v2d *)(Y + (long)t * a.N) + 4 * g + hh;
+            yo[0] = accr[j]; yo[2] = acci[j];
+        }
+    }
+}
+
+template <int D> static void launch_mac_lds_d2(const MacArgs &a, hipStream_t s)
+{
+    const int nbt = a.N / 8 / 32;              // bin tiles of 32 groups (two lanes per group)
+    const int nTQ = (a.n_t + 31) / 32;         // time tiles of 32 blocks
+    hipLaunchKernelGGL((k_mac_lds_d2<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+}
+
 template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
 {
     const int nbt = a.N / 8 / 64;              // bin tiles of 64 groups
@@ -1040,8 +1172,11 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         else if (tt >= 2) launch_mac_t<float, 2, 4, 1>(a, s);
         else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
-        static const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid
-        if (a.N >= 512 && tt >= 16 && v64 == 0) launch_mac_lds_d<2>(a, s);
+        const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid, read per launch
+        if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2<2>(a, s);      // two bins per lane, 32-block tiles
+        else if (a.N >= 512 && tt >= 32 && v64 == 4) launch_mac_lds_d2<4>(a, s);
+        else if (a.N >= 512 && tt >= 32 && v64 == 5) launch_mac_lds_d2<1>(a, s);
+        else if (a.N >= 512 && tt >= 16 && (v64 == 0 || v64 == 6)) launch_mac_lds_d<2>(a, s);
         else if (a.N >= 512 && tt >= 16 && v64 == 2) launch_mac_lds_d<4>(a, s);
         else if (a.N >= 512 && tt >= 16 && v64 == 3) launch_mac_lds_d<1>(a, s);
         else if (tt >= 4) launch_mac_t<double, 4, 1, 1>(a, s);   // 1 wave/SIMD: the 2-wave build spills to scratch

@@ -37,6 +37,81 @@ double orc_fmt_out_scale(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_
 double orc_fmt_max(int fmt) { return orc_fmt_isfloat(fmt) ? 1.0 : orc_fmt_full_scale(fmt) - 1.0; }
 
 /* ------------------------------------------------------------------ */
+/* optional: the real FFTW behind R2HC / HC2R         */
+/* ------------------------------------------------------------------ */
+/* When libfftw3f.so.3 / libfftw3.so.3 can be dlopen'ed on the host, orc_use_fftw(1) makes
+ * orc_r2hc / orc_hc2r execute FFTW r2r plans (FFTW_R2HC / FFTW_HC2R, FFTW_MEASURE as the
+ * reference plans them, brutefir/fftw_convolver.cpp:798-806) instead of this file's own FFT; the
+ * CPU baseline row of bench.py is then labelled "FFTW".  Nothing is downloaded or installed: absent
+ * library -> the switch stays off and the label says so.  Plans are made under a lock (the FFTW
+ * planner is not thread safe), executed with the new-array interface (thread safe). */
+#include <dlfcn.h>
+#include <pthread.h>
+typedef void *(*orc_fftw_plan_fn)(int, void *, void *, int, unsigned);
+typedef void (*orc_fftw_exec_fn)(void *, void *, void *);
+static struct {
+    int on;
+    orc_fftw_plan_fn plan_f, plan_d;
+    orc_fftw_exec_fn exec_f, exec_d;
+    void *plans[2][2][32];          /* [double?][HC2R?][log2 n] */
+    pthread_mutex_t lock;
+} g_fftw = {0, 0, 0, 0, 0, {{{0}}}, PTHREAD_MUTEX_INITIALIZER};
+
+int orc_use_fftw(int on)
+{
+    if (!on) { g_fftw.on = 0; return 0; }
+    if (!g_fftw.plan_f) {
+        void *hf = dlopen("libfftw3f.so.3", RTLD_NOW | RTLD_LOCAL), *hd = dlopen("libfftw3.so.3", RTLD_NOW | RTLD_LOCAL);
+        if (!hf || !hd) return 0;
+        g_fftw.plan_f = (orc_fftw_plan_fn)dlsym(hf, "fftwf_plan_r2r_1d");
+        g_fftw.exec_f = (orc_fftw_exec_fn)dlsym(hf, "fftwf_execute_r2r");
+        g_fftw.plan_d = (orc_fftw_plan_fn)dlsym(hd, "fftw_plan_r2r_1d");
+        g_fftw.exec_d = (orc_fftw_exec_fn)dlsym(hd, "fftw_execute_r2r");
+        if (!g_fftw.plan_f || !g_fftw.exec_f || !g_fftw.plan_d || !g_fftw.exec_d) { g_fftw.plan_f = 0; return 0; }
+    }
+    g_fftw.on = 1;
+    return 1;
+}
+
+/* plan of n reals; kind 0 = FFTW_R2HC, 1 = FFTW_HC2R; FFTW_MEASURE (0) | FFTW_UNALIGNED (2), and
+ * FFTW_PRESERVE_INPUT (16) for HC2R, whose callers here pass const input */
+static void *orc_fftw_plan(int is_double, int kind, int n)
+{
+    int lg = 0;
+    void *p;
+    while ((1 << lg) < n) lg++;
+    if (lg >= 32) return NULL;
+    pthread_mutex_lock(&g_fftw.lock);
+    p = g_fftw.plans[is_double][kind][lg];
+    if (!p) {
+        size_t sz = (size_t)n * (is_double ? 8 : 4);
+        void *a = malloc(sz), *b = malloc(sz);
+        memset(a, 0, sz);
+        p = (is_double ? g_fftw.plan_d : g_fftw.plan_f)(n, a, b, kind, 2u | (kind ? 16u : 0u));
+        free(a); free(b);
+        g_fftw.plans[is_double][kind][lg] = p;
+    }
+    pthread_mutex_unlock(&g_fftw.lock);
+    return p;
+}
+
+static int orc_fftw_run_f(int kind, int n, const float *in, float *out)
+{
+    void *p;
+    if (!g_fftw.on || !(p = orc_fftw_plan(0, kind, n))) return 0;
+    g_fftw.exec_f(p, (void *)in, out);
+    return 1;
+}
+
+static int orc_fftw_run_d(int kind, int n, const double *in, double *out)
+{
+    void *p;
+    if (!g_fftw.on || !(p = orc_fftw_plan(1, kind, n))) return 0;
+    g_fftw.exec_d(p, (void *)in, out);
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
 /* HP-TPDF dither: class dither (brutefir/dither.cpp)                   */
 /* ------------------------------------------------------------------ */
 /* dither_randmap (dither.cpp:73-104): difference of two table bytes -> dither value in [-1, +1]

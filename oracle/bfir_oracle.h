@@ -193,6 +193,11 @@ void orc_engine_get_overflow(const orc_engine *e, int channel, orc_overflow_t *o
 /* Pointer to partition spectrum `block` of channel `ch` (n_fft reals). */
 const void *orc_engine_coeff_block(const orc_engine *e, int ch, int block);
 
+/* ---- optional real FFTW behind orc_r2hc / orc_hc2r (CPU baseline row "FFTW") ----
+ * orc_use_fftw(1) -> 1 if libfftw3f.so.3 and libfftw3.so.3 could be dlopen'ed on this host and are now
+ * used (FFTW_MEASURE r2r plans, as brutefir/fftw_convolver.cpp:798-806 makes them), 0 otherwise (own FFT). */
+int orc_use_fftw(int on);
+
 /* ---- independent checker (not a restatement of anything) ----
  * Direct-form linear convolution in long double:
  *   y[n] = sum_k h[k] x[n-k],  n < n_x,  x[<0] = 0.   Inputs/outputs double. */

@@ -292,6 +292,17 @@ def direct_conv(x, h):
     return y
 
 
+def fft_backend(try_fftw=True):
+    """Which FFT the CPU baseline runs on: real FFTW r2r plans when libfftw3f.so.3 / libfftw3.so.3 can be
+    dlopen'ed on this host (nothing is ever installed), otherwise the oracle's own FFT."""
+    L = lib()
+    L.orc_use_fftw.restype = C.c_int
+    L.orc_use_fftw.argtypes = [C.c_int]
+    if try_fftw and L.orc_use_fftw(1):
+        return "FFTW (libfftw3f.so.3 / libfftw3.so.3, FFTW_MEASURE r2r plans)"
+    return "own CPU FFT (FFTW unavailable)"
+
+
 class Dither:
     """class dither (brutefir/dither.cpp): random table + per-channel state."""
 

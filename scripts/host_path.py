@@ -7,9 +7,10 @@ import foo_dsp_bfir_amd as bfir
 
 rng = np.random.default_rng(0)
 
-def engine(L, B, C):
-    e = bfir.Brutefir(L, B, 4, C)
-    e.set_coeff([(rng.standard_normal(L * B) * 0.01).astype(np.float32) for _ in range(C)])
+def engine(L, B, C, s=4, in_fmt=None, out_fmt=None):
+    e = bfir.Brutefir(L, B, s, C, in_fmt, out_fmt)
+    dt = np.float32 if s == 4 else np.float64
+    e.set_coeff([(rng.standard_normal(L * B) * 0.01).astype(dt) for _ in range(C)])
     return e
 
 # batched host call, headline shape
@@ -22,15 +23,20 @@ print("host-buffer run(): %d blocks of the headline shape in %.1f ms = %.2f Gsam
       % (nb, dt * 1e3, nb * L * C / dt / 1e9))
 e.close()
 
-# one block per call
-for (L, B, C) in [(1024, 64, 2), (4096, 32, 8)]:
-    e = engine(L, B, C)
-    blk = rng.uniform(-1, 1, (L, C)).astype(np.float32)
-    for _ in range(20): e.run(blk)
-    ts = []
-    for _ in range(200):
-        t0 = time.perf_counter(); e.run(blk); ts.append(time.perf_counter() - t0)
-    ts = np.array(ts) * 1e6
-    print("one run() per block, L=%d B=%d C=%d: median %.0f us, p95 %.0f us per call (block = %.1f ms of 44.1 kHz audio)"
-          % (L, B, C, np.median(ts), np.percentile(ts, 95), L / 44.1))
-    e.close()
+# one block per call: the plug-in's own shape first (REALSIZE 8, FILTER_LEN 1024, float32 frames, stereo), its fp32 sibling, the headline
+for (L, B, C, s) in [(1024, 64, 2, 8), (1024, 64, 2, 4), (4096, 32, 8, 4)]:
+    for small in (True, False):
+        if small: os.environ.pop("BFIR_NO_SMALL_RUN", None)
+        else: os.environ["BFIR_NO_SMALL_RUN"] = "1"
+        e = engine(L, B, C, s, 8, 8)                       # FLOAT_LE frames in and out (foo_dsp_bfir.cpp:283-284)
+        blk = rng.uniform(-1, 1, (L, C)).astype(np.float32)
+        out = np.empty_like(blk)
+        for _ in range(50): e.run(blk, out)
+        ts = []
+        for _ in range(400):
+            t0 = time.perf_counter(); e.run(blk, out); ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6
+        print("one run() per block, realsize %d L=%d B=%d C=%d, %s: median %.0f us, p95 %.0f us per call (block = %.1f ms of 44.1 kHz audio)"
+              % (s, L, B, C, "latency path" if small else "pipelined path (round 1)", np.median(ts), np.percentile(ts, 95), L / 44.1))
+        e.close()
+os.environ.pop("BFIR_NO_SMALL_RUN", None)

@@ -127,6 +127,12 @@ struct bfir_engine {
     // tails[set][i] = [n_eng][L][C] floats, set alternating per chunk so a launch never reads and
     // writes the same copy; hist_raw[i] is where input_timecbuf[n][i]'s first half currently lives.
     bool pair = false;
+    // direct path: any other engine whose frames are FLOAT_LE / FLOAT64_LE in and out (fp64 arithmetic, odd
+    // channel counts, partitions outside the pair kernels' range): k_fwd reads the raw frames itself and
+    // k_inv writes them, one channel per transform; same history bookkeeping as the pair path (tails of raw
+    // input frames), no staging kernels, no planar time buffers.  BFIR_DIRECT=0 / BFIR_PAIR=0 (tuning aids,
+    // tests) keep the staging kernels.
+    bool direct = false;
     FftPlan plan2;                         // transform of 2L complex points
     float *tails[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     const float *hist_raw[2] = {nullptr, nullptr};
@@ -203,7 +209,7 @@ static int alloc_work(bfir_engine *e, int chunk)
     HIP_TRY(hipMalloc(&X, (size_t)e->GC * ring * cb));
     HIP_TRY(hipMalloc(&Y0, (size_t)e->GC * chunk * cb));
     HIP_TRY(hipMalloc(&Y1, (size_t)e->GC * chunk * cb));
-    if (!e->pair) {   // the pair path has no planar time buffers
+    if (!e->pair && !e->direct) {   // the pair and direct paths have no planar time buffers
         HIP_TRY(hipMalloc(&tin0, (size_t)e->GC * chunk * e->L * e->s));
         HIP_TRY(hipMalloc(&tin1, (size_t)e->GC * chunk * e->L * e->s));
         HIP_TRY(hipMalloc(&tout, (size_t)e->GC * chunk * e->L * e->s));
@@ -269,6 +275,14 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         const char *pv = getenv("BFIR_PAIR");
         e->pair = e->ilv && in_format == 8 && out_format == 8 && (channels % 2) == 0 &&
                   pair_supported(filter_length) && !(pv && atoi(pv) == 0);
+        const char *dv = getenv("BFIR_DIRECT");
+        // worth it where a channel's samples are 8 bytes apart or wider units: FLOAT64 frames (any C), or one
+        // channel (contiguous samples).  4-byte samples at a stride (float frames, C > 1) are faster through the
+        // staging kernels, which move whole frames (profiles/r02_other_configs.txt: 11.4 vs 20.6 Gsamples/s for
+        // the plug-in's fp64-arithmetic / float-frame / stereo shape).  BFIR_DIRECT=1 forces it (tests).
+        const bool wide = (e->in_bytes == 8 && e->out_bytes == 8) || channels == 1;
+        e->direct = !e->pair && fmt_is_native(in_format) && fmt_is_native(out_format) && !(pv && atoi(pv) == 0) &&
+                    (dv ? atoi(dv) != 0 : wide);
     }
     if (const char *pm = getenv("BFIR_PIPE")) { e->pipe3 = atoi(pm) >= 3; e->serial = atoi(pm) == 1; }
     e->nblk.assign(e->GC, 0);
@@ -276,9 +290,9 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
     if (rc != 0) { *err = (rc == -1) ? BFIR_ERR_UNSUPPORTED : BFIR_ERR_HIP; delete e; return nullptr; }
     auto fail = [&](int code) { *err = code; bfir_engine_destroy(e); return (bfir_engine *)nullptr; };
-    if (e->pair) {
-        if (fft_plan_create(&e->plan2, 2 * filter_length, 4) != 0) return fail(BFIR_ERR_HIP);
-        const size_t tb = (size_t)e->n_eng * e->L * e->C * sizeof(float);
+    if (e->pair || e->direct) {
+        if (e->pair && fft_plan_create(&e->plan2, 2 * filter_length, 4) != 0) return fail(BFIR_ERR_HIP);
+        const size_t tb = (size_t)e->n_eng * e->L * e->C * e->in_bytes;     // raw input frames of one block
         for (int st = 0; st < 2; st++)
             for (int i = 0; i < 2; i++) {
                 if (hipMalloc((void **)&e->tails[st][i], tb) != hipSuccess) return fail(BFIR_ERR_HIP);
@@ -613,10 +627,84 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
     return BFIR_OK;
 }
 
+// The same chunk on the direct path: k_fwd / k_inv of the general path in direct mode (kernels.h).
+//   s_front : fwd(k)   raw frames -> delay-line spectrum, one channel per transform
+//   s_mac   : mac(k)
+//   st      : inv(k)   product spectrum -> raw frames + overflow statistics
+static int run_chunk_direct(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
+                            long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
+{
+    if (((uintptr_t)d_in | (uintptr_t)in_stride) % e->in_bytes || ((uintptr_t)d_out | (uintptr_t)out_stride) % e->out_bytes) {
+        bfir_logf("bfir engine: frame buffers must be aligned to their sample size.");
+        return BFIR_ERR_ARG;
+    }
+    const int par = (int)(e->chunk_seq & 1);
+    const int base_slot = (int)(e->blockcounter % (unsigned long long)e->ring);
+    const bool il = e->inline_launch;
+    hipStream_t sf = (e->serial || il) ? st : e->s_front;
+    hipStream_t sm = (e->pipe3 && !il) ? e->s_mac : st;
+    if (input_ready) HIP_TRY(hipStreamWaitEvent(sf, input_ready, 0));
+    if (!il && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sf, e->ev_mac[par], 0));   // mac(k-2) is done with the ring
+    const int idx_last = 1 ^ e->curbuf ^ ((tc - 1) & 1);
+    {
+        ProfScope ps(e, BFIR_K_FWD, sf);
+        FwdArgs a;
+        a.src = nullptr; a.src_ch_stride = 0; a.prev = nullptr; a.prev_ch_stride = 0;
+        a.dst = e->X; a.dst_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
+        a.n_t = tc; a.n_ch = e->GC;
+        a.load_scale = 1.0; a.out_scale = e->in_scale; a.zero_first_half = 0; a.interleaved = e->ilv;
+        a.raw_bytes = e->in_bytes; a.raw = d_in; a.raw_eng_stride = in_stride / e->in_bytes; a.frame_off = frame_off; a.C = e->C;
+        a.prev_raw = e->hist_raw[e->curbuf];
+        a.save_last = e->tails[par][idx_last]; a.save_prev = e->tails[par][1 ^ idx_last];
+        a.carry = e->hist_raw[1 ^ idx_last];
+        a.hist_eng_stride = (long)e->L * e->C;
+        launch_fwd(e->plan, a, sf);
+    }
+    e->hist_raw[0] = e->tails[par][0]; e->hist_raw[1] = e->tails[par][1];
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_fwd[par], sf));
+        HIP_TRY(hipStreamWaitEvent(sm, e->ev_fwd[par], 0));
+        if (e->pipe3 && e->chunk_seq >= 2) HIP_TRY(hipStreamWaitEvent(sm, e->ev_inv[par], 0));   // inv(k-2) has read Yb[par]
+    }
+    void *Y = e->Yb[e->pipe3 ? par : 0];
+    {
+        ProfScope ps(e, BFIR_K_MAC, sm);
+        MacArgs a;
+        a.x = e->X; a.x_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
+        a.h = e->H; a.h_ch_stride = (long)e->B * e->N;
+        a.nblk = e->d_nblk;
+        a.y = Y; a.y_ch_stride = (long)e->chunk * e->N;
+        a.n_t = tc; a.n_ch = e->GC; a.N = e->N; a.realsize = e->s; a.B = e->B;
+        a.interleaved = e->ilv;
+        launch_mac(a, sm);
+    }
+    if (!il) {
+        HIP_TRY(hipEventRecord(e->ev_mac[par], sm));
+        if (e->pipe3) HIP_TRY(hipStreamWaitEvent(st, e->ev_mac[par], 0));
+    }
+    {
+        ProfScope ps(e, BFIR_K_INV, st);
+        InvArgs a;
+        a.src = Y; a.src_ch_stride = (long)e->chunk * e->N;
+        a.dst = nullptr; a.dst_ch_stride = 0;
+        a.n_t = tc; a.n_ch = e->GC;
+        a.in_scale = e->out_scale; a.full_output = 0; a.interleaved = e->ilv;
+        a.raw_bytes = e->out_bytes; a.raw = d_out; a.raw_eng_stride = out_stride / e->out_bytes; a.frame_off = frame_off; a.C = e->C;
+        a.max = e->of_max; a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        launch_inv(e->plan, a, st);
+    }
+    if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
+    e->curbuf ^= (tc & 1);
+    e->blockcounter += (unsigned long long)tc;
+    e->chunk_seq += 1;
+    return BFIR_OK;
+}
+
 static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
                      long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
 {
     if (e->pair) return run_chunk_pair(e, d_in, in_stride, d_out, out_stride, frame_off, tc, block_base, st, input_ready);
+    if (e->direct) return run_chunk_direct(e, d_in, in_stride, d_out, out_stride, frame_off, tc, block_base, st, input_ready);
     const int par = (int)(e->chunk_seq & 1);
     const long t_stride = (long)e->chunk * e->L;
     void *tin = e->tin[par];

@@ -98,6 +98,15 @@ struct FwdArgs {
     double load_scale, out_scale;
     int zero_first_half;
     int interleaved = 0;           // spectrum layout: 0 = the reference's groups (4 re | 4 im), 1 = (re, im) pairs
+    // Direct mode (raw_bytes = 4 / 8, FLOAT_LE / FLOAT64_LE frames): the samples come straight from the
+    // interleaved raw frames instead of a planar buffer -- no staging kernel, no planar time buffers.
+    // Channel gc = g C + c reads frame f of engine g at raw + g raw_eng_stride + (frame_off + f) C + c (in
+    // samples); the block before block 0 is the raw-frame block prev_raw [n_eng][L][C]; the raw frames of the
+    // chunk's last two blocks are kept in save_last / save_prev as the pair path keeps them (pair.hip).
+    int raw_bytes = 0;
+    const void *raw = nullptr; long raw_eng_stride = 0, frame_off = 0; int C = 0;
+    const void *prev_raw = nullptr, *carry = nullptr; void *save_last = nullptr, *save_prev = nullptr;
+    long hist_eng_stride = 0;
 };
 void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s);
 
@@ -122,6 +131,12 @@ struct InvArgs {
     double in_scale;
     int full_output;                               // 1: write all N samples at stride N (stage API)
     int interleaved = 0;                           // layout of src, as in FwdArgs
+    // Direct mode (raw_bytes = 4 / 8): the valid half goes straight into the interleaved raw output frames
+    // (same addressing as FwdArgs) with the overflow statistics and the NaN guard of real2raw
+    // (brutefir/real2raw.cpp:321-336, brutefir.cpp:316-321): no planar output buffer, no staging kernel.
+    int raw_bytes = 0;
+    void *raw = nullptr; long raw_eng_stride = 0, frame_off = 0; int C = 0;
+    double max = 1.0; DevOverflow *overflow = nullptr; int *bad_block = nullptr; int block_base = 0;
 };
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
 

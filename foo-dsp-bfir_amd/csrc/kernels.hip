@@ -127,10 +127,15 @@ void fft_plan_destroy(FftPlan *plan)
     plan->tw = plan->ws = plan->twb = nullptr;
 }
 
+// |v| as an integer whose ordering equals the ordering of the magnitudes
+__device__ __forceinline__ unsigned int abs_bits(float v) { return __float_as_uint(fabsf(v)); }
+__device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+
 // ---------------------------------------------------------------------------
 // a6 + a7: forward real FFT into the grouped layout
 // ---------------------------------------------------------------------------
-template <typename T, int LOG2M, bool ILV>
+// TR: type of the raw samples in direct mode (FwdArgs.raw_bytes), void for the planar source
+template <typename T, int LOG2M, bool ILV, typename TR = void>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
                                                            const typename Vec2<T>::type *__restrict__ tw,
                                                            const typename Vec2<T>::type *__restrict__ ws)
@@ -142,7 +147,14 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
     __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
 
     const int tid = threadIdx.x;
-    const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
+    constexpr bool DIRECT = !std::is_void<TR>::value;
+    // direct mode: the channels of a block share input cache lines -> give every XCD a contiguous range
+    int wi = blockIdx.x;
+    if constexpr (DIRECT) {
+        const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+        wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    }
+    const int t = wi / a.n_ch, gc = wi - t * a.n_ch;
     const T *__restrict__ cur = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * M;
     const T *__restrict__ old = (t == 0) ? (const T *)a.prev + (long)gc * a.prev_ch_stride : cur - M;
     T *__restrict__ dst =
@@ -152,6 +164,34 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
     // z[m] = x[2m] + i x[2m+1] over the window [previous block | this block]
     T re[P], im[P];
     const T ls = (T)a.load_scale;
+    if constexpr (DIRECT) {
+        using RS = typename std::conditional<DIRECT, TR, float>::type;
+        const int C = a.C, g = gc / C, c = gc - g * C;
+        const long ho = (long)g * a.hist_eng_stride + c;
+        const RS *__restrict__ rc = (const RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c;
+        const RS *__restrict__ ro = (t == 0) ? (const RS *)a.prev_raw + ho : rc - (long)M * C;
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int m = F::in_index(tid, e);
+            if (m < M / 2) {                                   // frames 2m, 2m+1 of the previous block
+                const RS x0 = ro[(long)(2 * m) * C], x1 = ro[(long)(2 * m + 1) * C];
+                re[e] = (T)x0 * ls; im[e] = (T)x1 * ls;
+                if (a.n_t == 1) {                              // one-block chunk: the other history block moves on unchanged
+                    RS *sp = (RS *)a.save_prev + ho; const RS *cr = (const RS *)a.carry + ho;
+                    sp[(long)(2 * m) * C] = cr[(long)(2 * m) * C]; sp[(long)(2 * m + 1) * C] = cr[(long)(2 * m + 1) * C];
+                }
+            } else {                                           // frames of this block
+                const int n = 2 * m - M;
+                const RS x0 = rc[(long)n * C], x1 = rc[(long)(n + 1) * C];
+                re[e] = (T)x0 * ls; im[e] = (T)x1 * ls;
+                // the engine's history: raw frames of the last two blocks of the chunk
+                if (t >= a.n_t - 2) {
+                    RS *kp = (RS *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho;
+                    kp[(long)n * C] = x0; kp[(long)(n + 1) * C] = x1;
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int e = 0; e < P; e++) {
         const int m = F::in_index(tid, e);
@@ -223,6 +263,16 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
     // a transform whose LDS buffer would not fit one CU is never instantiated
     if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
     {
+        if (a.raw_bytes) {           // direct mode: raw float / double frames in
+            const bool il = sizeof(T) == 4 && a.interleaved;
+#define BFIR_LAUNCH_FWD_RAW(IL_, TR_) hipLaunchKernelGGL((k_fwd<T, LOG2M, IL_, TR_>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const V2 *)plan.tw, (const V2 *)plan.ws)
+            if constexpr (sizeof(T) == 4) {
+                if (il) { if (a.raw_bytes == 4) BFIR_LAUNCH_FWD_RAW(true, float); else BFIR_LAUNCH_FWD_RAW(true, double); return; }
+            }
+            if (a.raw_bytes == 4) BFIR_LAUNCH_FWD_RAW(false, float); else BFIR_LAUNCH_FWD_RAW(false, double);
+#undef BFIR_LAUNCH_FWD_RAW
+            return;
+        }
         if constexpr (sizeof(T) == 4) {
             if (a.interleaved) {
                 hipLaunchKernelGGL((k_fwd<T, LOG2M, true>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
@@ -253,7 +303,7 @@ void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // a11 + a12: inverse real FFT from the grouped layout, valid half only
 // ---------------------------------------------------------------------------
-template <typename T, int LOG2M, bool ILV>
+template <typename T, int LOG2M, bool ILV, typename TR = void>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
                                                            const typename Vec2<T>::type *__restrict__ tw,
                                                            const typename Vec2<T>::type *__restrict__ ws)
@@ -265,7 +315,13 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
     __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
 
     const int tid = threadIdx.x;
-    const int t = blockIdx.x / a.n_ch, gc = blockIdx.x - t * a.n_ch;
+    constexpr bool DIRECT = !std::is_void<TR>::value;
+    int wi = blockIdx.x;
+    if constexpr (DIRECT) {       // the channels of a block write the same cache lines: one XCD
+        const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+        wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    }
+    const int t = wi / a.n_ch, gc = wi - t * a.n_ch;
     const T *__restrict__ src = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * N;
     T *__restrict__ dst =
         (T *)a.dst + (long)gc * a.dst_ch_stride + (long)t * (a.full_output ? N : M);
@@ -306,6 +362,48 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
     BFIR_STAMP(1, 1);
     F::run(re, im, lds, tw, tid);
 
+    if constexpr (DIRECT) {
+        // valid half -> raw output frames of this channel, with real2raw's bookkeeping
+        using RS = typename std::conditional<DIRECT, TR, float>::type;
+        using Bits = decltype(abs_bits((T)0));
+        __shared__ Bits red_max[NT / 64 > 0 ? NT / 64 : 1];
+        __shared__ unsigned int red_cnt[NT / 64 > 0 ? NT / 64 : 1];
+        const int C = a.C, g = gc / C, c = gc - g * C;
+        RS *__restrict__ out = (RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c;
+        const T rmax = (T)a.max, rmin = (T)(-a.max);
+        Bits mx = 0; unsigned int cnt = 0u;
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int m = F::out_index(tid, e);
+            if (m < M / 2) {
+                const T v0 = re[e], v1 = im[e];
+                out[(long)(2 * m) * C] = (RS)v0; out[(long)(2 * m + 1) * C] = (RS)v1;
+                // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+                cnt += ((v0 < (T)0) ? (v0 < rmin) : (v0 > rmax)) ? 1u : 0u;
+                cnt += ((v1 < (T)0) ? (v1 < rmin) : (v1 > rmax)) ? 1u : 0u;
+                const Bits b0 = (v0 == v0) ? abs_bits(v0) : (Bits)0, b1 = (v1 == v1) ? abs_bits(v1) : (Bits)0;
+                mx = b0 > mx ? b0 : mx; mx = b1 > mx ? b1 : mx;
+                // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+                if (m == 0 && !isfinite((double)v0)) atomicMin(a.bad_block, a.block_base + t);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const Bits om = __shfl_xor(mx, o);
+            mx = om > mx ? om : mx;
+            cnt += __shfl_xor(cnt, o);
+        }
+        if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_cnt[tid >> 6] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            Bits m2 = 0; unsigned int n2 = 0u;
+            for (int wv = 0; wv < (NT + 63) / 64; wv++) { m2 = red_max[wv] > m2 ? red_max[wv] : m2; n2 += red_cnt[wv]; }
+            DevOverflow *of = a.overflow + gc;
+            if (n2) atomicAdd(&of->n_overflows, n2);
+            if ((unsigned long long)m2 > *(volatile unsigned long long *)&of->largest_bits)
+                atomicMax(&of->largest_bits, (unsigned long long)m2);
+        }
+    } else
 #pragma unroll
     for (int e = 0; e < P; e++) {
         const int m = F::out_index(tid, e);
@@ -323,6 +421,16 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
     // a transform whose LDS buffer would not fit one CU is never instantiated
     if constexpr (sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 160 * 1024)
     {
+        if (a.raw_bytes) {           // direct mode: raw float / double frames out
+            const bool il = sizeof(T) == 4 && a.interleaved;
+#define BFIR_LAUNCH_INV_RAW(IL_, TR_) hipLaunchKernelGGL((k_inv<T, LOG2M, IL_, TR_>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const V2 *)plan.tw, (const V2 *)plan.ws)
+            if constexpr (sizeof(T) == 4) {
+                if (il) { if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RAW(true, float); else BFIR_LAUNCH_INV_RAW(true, double); return; }
+            }
+            if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RAW(false, float); else BFIR_LAUNCH_INV_RAW(false, double);
+#undef BFIR_LAUNCH_INV_RAW
+            return;
+        }
         if constexpr (sizeof(T) == 4) {
             if (a.interleaved) {
                 hipLaunchKernelGGL((k_inv<T, LOG2M, true>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
@@ -1311,9 +1419,6 @@ void launch_stage_in(const StageInArgs &a, hipStream_t s)
     else launch_stage_in_t<double, double>(a, grid, wb, s);
 }
 
-// |v| as an integer whose ordering equals the ordering of the magnitudes
-__device__ __forceinline__ unsigned int abs_bits(float v) { return __float_as_uint(fabsf(v)); }
-__device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
 template <typename T, typename TR, int WB> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_out(StageOutArgs a)
 {

@@ -439,6 +439,9 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
         }
         // the next transform's first exchange starts with a barrier, which also protects these LDS reads
     }
+    // The last prefetch (zero-byte descriptor: it returns zeros) is still in flight and will write nxt[]:
+    // those registers must not be handed to anything else before it has landed.
+    asm_wait_vmcnt<0>(nxt);
 }
 
 // ---- persistent inverse kernel ---------------------------------------------------------------------
@@ -570,6 +573,10 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
             }
         }
     }
+    // The last prefetch (zero-byte descriptors: it returns zeros) is still in flight and will write qa / qb.
+    // Without this wait the compiler reuses those registers below -- for the ADDRESSES of the atomics, which the
+    // late zeros then turn into a null pointer (seen as a sporadic "memory access fault on address (nil)").
+    asm_wait_vmcnt<0>(qa, qb);
     if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

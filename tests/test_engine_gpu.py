@@ -235,3 +235,39 @@ def test_create_rejects_bad_arguments(bfir):
             bfir.Brutefir(*args)
     with pytest.raises(bfir.BfirError):
         bfir.Brutefir(1024, 2, 4, 2, in_format=12)  # not a BF_SAMPLE_FORMAT_* code
+
+
+@pytest.mark.parametrize("s,L,B,C,in_fmt,out_fmt", [(8, 1024, 5, 2, 8, 8),     # the plug-in: REALSIZE 8, float32 frames
+                                                   (8, 256, 3, 3, 10, 10), (4, 256, 4, 3, 8, 8), (4, 16384, 2, 1, 8, 10),
+                                                   (8, 4096, 2, 5, 10, 8), (4, 64, 3, 2, 8, 8)])
+def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, in_fmt, out_fmt):
+    """Engines outside the float fast path whose frames are FLOAT_LE / FLOAT64_LE read and write the raw frames
+    from inside k_fwd / k_inv (direct mode) instead of through k_stage_in / k_stage_out and planar buffers:
+    the same arithmetic, so the same bits -- across chunked launches, one-block calls, reset and the
+    overflow bookkeeping -- and within tolerance of the oracle."""
+    import os
+    nb = 13
+    rng = np.random.default_rng(L + C)
+    h = orc.synth_ir(rng, C, B * L - 7, orc.real_dtype(s))
+    x = (orc.synth_audio(rng, nb * L, C, np.float64) * 1.7).astype(orc.fmt_dtype(in_fmt))   # some samples overflow 1.0
+    outs = []
+    for direct in (True, False):
+        os.environ["BFIR_DIRECT"] = "1" if direct else "0"   # 1 forces it where the engine would not pick it itself
+        try:
+            eng = bfir.Brutefir(L, B, s, C, in_fmt, out_fmt)
+        finally:
+            os.environ.pop("BFIR_DIRECT", None)
+        eng.set_chunk(4)
+        assert eng.set_coeff(h, scale=12.0) == 0
+        parts = [eng.run(x[a * L:b * L])[1] for a, b in ((0, 6), (6, 7), (7, nb))]
+        stats = [(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(C)]
+        eng.reset()
+        parts.append(eng.run(x[:3 * L])[1])
+        stats += [(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(C)]
+        outs.append((np.concatenate(parts), stats))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert all(big > 0.0 for _, big in outs[0][1][:C])          # the peak bookkeeping ran (counts depend on the data)
+    ref = orc.Engine(L, B, s, C, in_fmt, out_fmt); ref.set_coeff(h, scale=12.0)
+    y_ref = ref.run(x)[1]
+    assert rel_err(outs[0][0][:nb * L], y_ref) <= (1e-5 if (s == 4 or out_fmt == 8) else 1e-12)

@@ -153,6 +153,9 @@ GEOMETRIES = [
     ("cfg5_fp64_1024", 8, 4096, 64, 2, 1, 1024, [1024, 1024, 100], 1024, {}),
     # configs[3] in small: 8 stereo engines sharing launches, PB = 16
     ("cfg4_batch8", 4, 4096, 16, 2, 8, 1024, [1024, 1024, 64], 1024, {}),
+    # the plug-in's shape on the float fast path, eight launches per call (persistent pair kernels at N = 2048;
+    # a sporadic fault in their epilogue was found at exactly this shape in round 2)
+    ("plugin_stereo_8_launches", 4, 1024, 64, 2, 1, 4096, [4096, 100], 512, {}),
     # configs[1]: largest pair-path partition
     ("cfg2_L8192", 4, 8192, 8, 2, 1, 1024, [1024, 1024, 3], 1024, {}),
 ]

@@ -199,7 +199,8 @@ def spawn_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():          # stdout carries the JSON line only; library chatter (gloo) goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -240,7 +241,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="total independent engines dealt out to the ranks (0 = one per rank); "
                          "configs[3]: --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 1024")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="no oracle at all: neither the CPU timing nor the parity check")
+    ap.add_argument("--no-cpu-timing", action="store_true", help="keep the parity check of the timed output, skip the CPU timing")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and latency_one_block_us")
     ap.add_argument("--no-exclusive-pass", action="store_true",
                     help="skip the untimed serial-schedule pass (rocprofv3 runs: keeps the kernel trace to the overlapped schedule)")
@@ -518,7 +520,7 @@ def main():
                             v["traffic_rate_exclusive_GBs"] = round(v["traffic"] / (ex[kname] * 1e-3) / 1e9, 1)
         cpu = None
         extras = {}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not args.no_cpu_timing and world == 1:
             from oracle import oracle as O
             nb_cpu = min(nb, 4096)
             x_cpu = d_in[0, :nb_cpu * L].cpu().numpy()

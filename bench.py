@@ -60,6 +60,9 @@ WORKLOADS = {
     "plugin_8ch_98304tap_L1024_fp32": (8, 98304, 1024, 4),
     "plugin_2ch_65536tap_L1024_fp64": (2, 65536, 1024, 8),    # the shipped REALSIZE 8 (common.h:17-19)
     "plugin_2ch_65536tap_L1024_fp32": (2, 65536, 1024, 4),
+    # ... with the frames the plug-in really hands over: FLOAT_LE (32-bit) in and out around fp64 arithmetic
+    # (foo_dsp_bfir.cpp:279-289); fifth field = frame sample bytes
+    "plugin_2ch_65536tap_L1024_fp64_f32frames": (2, 65536, 1024, 8, 4),
 }
 
 
@@ -311,10 +314,12 @@ def main():
     import foo_dsp_bfir_amd as bfir   # raises if the HIP library is missing
     from foo_dsp_bfir_amd import sharding
 
-    C_all, taps, L, s = WORKLOADS[args.workload]
+    C_all, taps, L, s = WORKLOADS[args.workload][:4]
+    fb = WORKLOADS[args.workload][4] if len(WORKLOADS[args.workload]) > 4 else s     # bytes per frame sample
+    fmt = 8 if fb == 4 else 10                                                          # BF_SAMPLE_FORMAT_FLOAT_LE / FLOAT64_LE
     N, B = 2 * L, (taps + L - 1) // L
     rdt = np.float32 if s == 4 else np.float64
-    tdt = torch.float32 if s == 4 else torch.float64
+    tdt = torch.float32 if fb == 4 else torch.float64
     # Units.  replicas: independent streams, one per rank (weak).  channels: the channels of ONE
     # stream (strong).  --streams S: S engines dealt out to the ranks (strong, configs[3]).
     ch_lo, ch_hi = 0, C_all
@@ -353,11 +358,11 @@ def main():
                 g.manual_seed(7 + 1000 * (first_stream + k) + (ch_lo + c))
                 d_in[k, :, c].uniform_(-1.0, 1.0, generator=g)
         d_out = torch.empty_like(d_in)
-        eng = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
+        eng = bfir.Brutefir(L, B, s, C, fmt, fmt, device=local, n_engines=n_eng)
         eng.set_chunk(chunk)
         for k in range(n_eng):
             assert eng.set_coeff(hs[k], engine_index=k) == 0
-    eng_stride = nb * L * C * s
+    eng_stride = nb * L * C * fb
     stream = torch.cuda.current_stream()
 
     def step():
@@ -406,12 +411,12 @@ def main():
 
         def in_block(k, g):
             if g < 0:
-                return np.zeros((L, C), rdt)
+                return np.zeros((L, C), np.float32 if fb == 4 else np.float64)
             t = g % nb
             return d_in[k, t * L:(t + 1) * L].cpu().numpy()
         worst = 0.0
         for k in sorted({0, n_eng - 1}):
-            ref = O.sampled_reference(hs[k], lambda g: in_block(k, g), [g_base + t for t in cand], L, B, s, C)
+            ref = O.sampled_reference(hs[k], lambda g: in_block(k, g), [g_base + t for t in cand], L, B, s, C, fmt, fmt)
             for t in cand:
                 y = d_out[k, t * L:(t + 1) * L].cpu().numpy().astype(np.float64)
                 r = ref[g_base + t].astype(np.float64)
@@ -420,14 +425,14 @@ def main():
         parity_note = ("%d sampled blocks of the timed output buffer (last step; first/last block, launch and "
                        "MAC-range boundaries, middle) of %d engine(s), each vs the oracle fed the B+1 input "
                        "blocks ending at it" % (len(cand), len({0, n_eng - 1})))
-        assert parity <= (1e-5 if s == 4 else 1e-12), parity
+        assert parity <= (1e-5 if min(s, fb) == 4 else 1e-12), parity
 
     # untimed extra pass for the roofline object: the same engine configuration on a serial schedule
     exclusive = None
     if eng is not None and rank == 0 and not args.no_kernel_events and not args.no_exclusive_pass:
         os.environ["BFIR_PIPE"] = "1"
         try:
-            ser = bfir.Brutefir(L, B, s, C, device=local, n_engines=n_eng)
+            ser = bfir.Brutefir(L, B, s, C, fmt, fmt, device=local, n_engines=n_eng)
         finally:
             del os.environ["BFIR_PIPE"]
         ser.set_chunk(chunk)

@@ -277,10 +277,14 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
                   pair_supported(filter_length) && !(pv && atoi(pv) == 0);
         const char *dv = getenv("BFIR_DIRECT");
         // worth it where a channel's samples are 8 bytes apart or wider units: FLOAT64 frames (any C), or one
-        // channel (contiguous samples).  4-byte samples at a stride (float frames, C > 1) are faster through the
-        // staging kernels, which move whole frames (profiles/r02_other_configs.txt: 11.4 vs 20.6 Gsamples/s for
-        // the plug-in's fp64-arithmetic / float-frame / stereo shape).  BFIR_DIRECT=1 forces it (tests).
-        const bool wide = (e->in_bytes == 8 && e->out_bytes == 8) || channels == 1;
+        // channel (contiguous samples), or stereo float frames (the reference plug-in's own shape), which k_fwd /
+        // k_inv move as whole frames with both channels in one workgroup.  Other 4-byte samples at a stride
+        // (float frames, C > 2) are faster through the staging kernels (profiles/r02_other_configs.txt: one
+        // channel per workgroup ran the plug-in's shape at 11.4 instead of 20.6 Gsamples/s).  BFIR_DIRECT=1
+        // forces it (tests).
+        const bool stereo = e->in_bytes == 4 && e->out_bytes == 4 && channels == 2 && !e->ilv &&
+                            direct_stereo_supported(filter_length, realsize);
+        const bool wide = (e->in_bytes == 8 && e->out_bytes == 8) || channels == 1 || stereo;
         e->direct = !e->pair && fmt_is_native(in_format) && fmt_is_native(out_format) && !(pv && atoi(pv) == 0) &&
                     (dv ? atoi(dv) != 0 : wide);
     }
@@ -314,7 +318,7 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         hipMalloc(&e->saved[0], (size_t)e->GC * Ls) != hipSuccess ||
         hipMalloc(&e->saved[1], (size_t)e->GC * Ls) != hipSuccess ||
         hipMalloc((void **)&e->d_nblk, sizeof(int) * e->GC) != hipSuccess ||
-        hipMalloc((void **)&e->d_of, sizeof(DevOverflow) * e->GC) != hipSuccess ||
+        hipMalloc((void **)&e->d_of, sizeof(DevOverflow) * e->GC * BFIR_OF_SHARDS) != hipSuccess ||
         hipMalloc((void **)&e->d_bad, sizeof(int)) != hipSuccess)
         return fail(BFIR_ERR_HIP);
     (void)hipMemset(e->H, 0, (size_t)e->GC * e->B * cb);
@@ -323,7 +327,7 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         e->hist[i].ptr = e->saved[i]; e->hist[i].ch_stride = e->L;
     }
     (void)hipMemset(e->d_nblk, 0, sizeof(int) * e->GC);
-    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
+    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC * BFIR_OF_SHARDS);
     (void)hipMemset(e->d_bad, 0x7f, sizeof(int));
     if (apply_dither && !fmt_info(out_format).isfloat) {
         // dither::dither(n_channels, sampling_rate, realsize, max_dither_table_size = 0, filter_length, state)
@@ -617,7 +621,7 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.raw = (float *)d_out; a.eng_stride = out_stride / 4; a.frame_off = frame_off;
         a.C = e->C; a.n_eng = e->n_eng; a.n_t = tc;
         a.scale = (float)e->out_scale; a.max = (float)e->of_max;
-        a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
         launch_inv_pair(e->plan2, a, st);
     }
     if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
@@ -690,7 +694,7 @@ static int run_chunk_direct(bfir_engine *e, const void *d_in, long in_stride, vo
         a.n_t = tc; a.n_ch = e->GC;
         a.in_scale = e->out_scale; a.full_output = 0; a.interleaved = e->ilv;
         a.raw_bytes = e->out_bytes; a.raw = d_out; a.raw_eng_stride = out_stride / e->out_bytes; a.frame_off = frame_off; a.C = e->C;
-        a.max = e->of_max; a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.max = e->of_max; a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
         launch_inv(e->plan, a, st);
     }
     if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
@@ -782,7 +786,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.n_frames = (long)tc * e->L;
         a.src = e->tout; a.src_ch_stride = t_stride;
         a.realsize = e->s; a.L = e->L; a.max = e->of_max;
-        a.overflow = e->d_of; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
         a.dither_tab = e->d_dither_tab; a.dither_size = e->dither_size; a.dither_state = e->d_dither_state;
         launch_stage_out(a, st);
     }
@@ -989,7 +993,7 @@ extern "C" void bfir_engine_reset(bfir_engine *e)
     // zeroed ring reproduces; the time-domain history is NOT cleared, so both
     // input_timecbuf halves are kept (copied out of the work buffers).
     (void)materialise_history(e);
-    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC);
+    (void)hipMemset(e->d_of, 0, sizeof(DevOverflow) * e->GC * BFIR_OF_SHARDS);
     // block t < B-1 of the new run still reads slots (t - i) mod ring, i > t: the B-1 slots at the top of
     // every channel's ring.  Only those need to read as zero; the rest is rewritten before it is read.
     if (e->B > 1) {
@@ -1007,8 +1011,17 @@ extern "C" int bfir_engine_get_overflow(bfir_engine *e, int channel, bfir_overfl
     if (!e || !of || channel < 0 || channel >= e->GC) return BFIR_ERR_ARG;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    DevOverflow d;
-    HIP_TRY(hipMemcpy(&d, e->d_of + channel, sizeof(d), hipMemcpyDeviceToHost));
+    // the copies of the counters (kernels.h, BFIR_OF_SHARDS): counts add up, peaks are maxima (the bit patterns of
+    // non-negative floats order like integers); the dither kernel keeps its running state in copy 0
+    std::vector<DevOverflow> all((size_t)e->GC * BFIR_OF_SHARDS);
+    HIP_TRY(hipMemcpy(all.data(), e->d_of, all.size() * sizeof(DevOverflow), hipMemcpyDeviceToHost));
+    DevOverflow d = all[channel];
+    for (int sh = 1; sh < BFIR_OF_SHARDS; sh++) {
+        const DevOverflow &o = all[(size_t)sh * e->GC + channel];
+        d.n_overflows += o.n_overflows;
+        d.intlargest = std::max(d.intlargest, o.intlargest);
+        d.largest_bits = std::max(d.largest_bits, o.largest_bits);
+    }
     of->n_overflows = d.n_overflows;
     of->intlargest = d.intlargest;
     if (e->s == 4) {

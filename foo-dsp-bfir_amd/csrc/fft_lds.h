@@ -333,29 +333,90 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
         butterflies<S>(re, im, w);
     }
 
+    // Logical LDS index of output q of butterfly b after pass S / of input r of butterfly b before pass S+1.
+    template <int S> __host__ __device__ static constexpr int widx(int tid, int b, int q)
+    {
+        const int R = radix(S), p = pprod(S);
+        const int i = tid + b * NT, k = i & (p - 1);
+        return (i - k) * R + k + q * p;
+    }
+    template <int S> __host__ __device__ static constexpr int ridx(int tid, int b, int r)
+    {
+        return (tid + b * NT) + r * (M / radix(S + 1));
+    }
+    // Is phys(index(tid, b, q)) = phys(index(tid, 0, 0)) + a compile-time constant for EVERY thread?  Then an
+    // exchange costs one address per thread and direction, the rest are immediate offsets of the LDS
+    // instructions.  (The compiler cannot see it through i + (i >> 5) and otherwise spends two VALU
+    // instructions per access: a fifth of the persistent pair kernels' vector instructions.)  Checked
+    // exhaustively at compile time; sizes that fail keep the per-access form.
+    template <int S> __host__ __device__ static constexpr bool wr_affine()
+    {
+        for (int b = 0; b < P / radix(S); b++)
+            for (int q = 0; q < radix(S); q++) {
+                const int off = phys(widx<S>(0, b, q)) - phys(widx<S>(0, 0, 0));
+                for (int t = 1; t < NT; t++)
+                    if (phys(widx<S>(t, b, q)) - phys(widx<S>(t, 0, 0)) != off) return false;
+            }
+        return true;
+    }
+    template <int S> __host__ __device__ static constexpr bool rd_affine()
+    {
+        for (int b = 0; b < P / radix(S + 1); b++)
+            for (int r = 0; r < radix(S + 1); r++) {
+                const int off = phys(ridx<S>(0, b, r)) - phys(ridx<S>(0, 0, 0));
+                for (int t = 1; t < NT; t++)
+                    if (phys(ridx<S>(t, b, r)) - phys(ridx<S>(t, 0, 0)) != off) return false;
+            }
+        return true;
+    }
+
     // write the outputs of pass S to LDS and fetch the inputs of pass S+1
     template <int S>
     __device__ __forceinline__ static void exchange(T *re, T *im, V2 *lds, int tid)
     {
-        constexpr int R = radix(S), p = pprod(S), Rn = radix(S + 1);
+        constexpr int R = radix(S), Rn = radix(S + 1);
         __syncthreads();  // earlier readers of lds are done
+        if constexpr (wr_affine<S>()) {
+            V2 *wp = lds + phys(widx<S>(tid, 0, 0));
+            static_for<0, P / R>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                static_for<0, R>([&](auto Q_) {
+                    constexpr int q = decltype(Q_)::value;
+                    constexpr int off = phys(widx<S>(0, b, q)) - phys(widx<S>(0, 0, 0));
+                    V2 v; v.x = re[b * R + Dft<R, SIGN, T>::pos(q)]; v.y = im[b * R + Dft<R, SIGN, T>::pos(q)];
+                    wp[off] = v;
+                });
+            });
+        } else {
 #pragma unroll
-        for (int b = 0; b < P / R; b++) {
-            const int i = tid + b * NT, k = i & (p - 1);
+            for (int b = 0; b < P / R; b++)
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                V2 v; v.x = re[b * R + Dft<R, SIGN, T>::pos(q)]; v.y = im[b * R + Dft<R, SIGN, T>::pos(q)];
-                lds[phys((i - k) * R + k + q * p)] = v;
-            }
+                for (int q = 0; q < R; q++) {
+                    V2 v; v.x = re[b * R + Dft<R, SIGN, T>::pos(q)]; v.y = im[b * R + Dft<R, SIGN, T>::pos(q)];
+                    lds[phys(widx<S>(tid, b, q))] = v;
+                }
         }
         __syncthreads();
+        if constexpr (rd_affine<S>()) {
+            const V2 *rp = lds + phys(ridx<S>(tid, 0, 0));
+            static_for<0, P / Rn>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                static_for<0, Rn>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    constexpr int off = phys(ridx<S>(0, b, r)) - phys(ridx<S>(0, 0, 0));
+                    const V2 v = rp[off];
+                    re[b * Rn + r] = v.x; im[b * Rn + r] = v.y;
+                });
+            });
+        } else {
 #pragma unroll
-        for (int b = 0; b < P / Rn; b++)
+            for (int b = 0; b < P / Rn; b++)
 #pragma unroll
-            for (int r = 0; r < Rn; r++) {
-                V2 v = lds[phys((tid + b * NT) + r * (M / Rn))];
-                re[b * Rn + r] = v.x; im[b * Rn + r] = v.y;
-            }
+                for (int r = 0; r < Rn; r++) {
+                    V2 v = lds[phys(ridx<S>(tid, b, r))];
+                    re[b * Rn + r] = v.x; im[b * Rn + r] = v.y;
+                }
+        }
         // the reads must not sink below the next barrier (see pin_registers)
 #pragma unroll
         for (int e = 0; e < P; e++) asm volatile("" : "+v"(re[e]), "+v"(im[e]));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -15,6 +16,15 @@ struct DevOverflow {
     int intlargest;                    // integer outputs: largest unclipped |sample|
     unsigned long long largest_bits;   // bit pattern of max |y| (float widened, or double)
 };
+// The engine keeps BFIR_OF_SHARDS copies of its per-channel counters and every workgroup updates the copy
+// blockIdx.x mod BFIR_OF_SHARDS (args.of_shard_stride elements apart; 0 = a single copy): when the output clips,
+// every workgroup adds to n_overflows, and same-address atomics from a hundred thousand workgroups ran the
+// plug-in's own shape at half speed.  bfir_engine_get_overflow sums / maximises over the copies.
+constexpr int BFIR_OF_SHARDS = 64;
+__device__ __forceinline__ DevOverflow *of_shard(DevOverflow *base, long shard_stride)
+{
+    return base + (long)(blockIdx.x & (BFIR_OF_SHARDS - 1)) * shard_stride;
+}
 
 // Sample formats (brutefir/global.h:24-34; table of brutefir.cpp:435-538, little-endian host).
 struct FmtInfo { int bytes; bool isfloat; bool big_endian; };
@@ -69,6 +79,7 @@ struct StageOutArgs {
     int L;                         // block length: sample 0 of every block is NaN-checked
     double max;                    // bfoverflow_t.max
     DevOverflow *overflow;         // [n_eng*C]
+    long of_shard_stride = 0;
     int *bad_block;                // atomicMin of the first block with a non-finite sample 0
     int block_base;                // index of the chunk's first block within the run
     int fmt = 0;                   // BF_SAMPLE_FORMAT_* code; 0 = FLOAT_LE / FLOAT64_LE by raw_bytes
@@ -119,7 +130,31 @@ struct MacArgs {
     int n_t, n_ch, N, realsize;
     int B = 0;                                     // partitions allocated per channel (max of nblk)
     int interleaved = 0;                           // layout of x, h and y, as in FwdArgs (fp32 streaming kernel only)
+#ifdef BFIR_EXPERIMENT_ALIAS
+    int y_alias = 1 << 30;                         // timing experiment: product spectrum t lives in slot t % y_alias
+#endif
 };
+// Cache policy of the two big streams, the delay line X and the product spectra Y (each written once and read
+// once, a gigabyte apart): bit 0 = stores nontemporal, bit 1 = loads nontemporal (-DBFIR_NT_X=n / -DBFIR_NT_Y=n;
+// persistent pair kernels and the streaming MAC).  All four on is the product setting: +4 % on the headline
+// pipeline (112.1 vs 107.5 Gsamples/s, same box; any three of them +1.5..3 %, profiles/r02_nt_policy.txt) --
+// the lines of the interleaved input / output frames, of which every workgroup uses a quarter, then
+// survive in L2 until the other three channel pairs have come by.  No effect on small launches.
+#ifndef BFIR_NT_X
+#define BFIR_NT_X 3
+#endif
+#ifndef BFIR_NT_Y
+#define BFIR_NT_Y 3
+#endif
+#ifdef BFIR_EXPERIMENT_ALIAS
+// Timing experiment (scripts/gpu_alias_exp.sh): BFIR_X_ALIAS / BFIR_Y_ALIAS fold the delay line / the product
+// spectra into that many slots, so that they stay in the caches.  Results are garbage; instruction streams
+// and launch geometry are those of the product build.  Never defined in the product library.
+#define BFIR_YSLOT(a, t) ((t) % (a).y_alias)
+inline int bfir_alias_env(const char *name) { const char *e = getenv(name); return e && atoi(e) > 0 ? atoi(e) : 0; }
+#else
+#define BFIR_YSLOT(a, t) (t)
+#endif
 void launch_mac(const MacArgs &a, hipStream_t s);
 
 // a11 + a12: inverse real FFT of Y[gc][t] (grouped layout, times in_scale),
@@ -137,12 +172,15 @@ struct InvArgs {
     int raw_bytes = 0;
     void *raw = nullptr; long raw_eng_stride = 0, frame_off = 0; int C = 0;
     double max = 1.0; DevOverflow *overflow = nullptr; int *bad_block = nullptr; int block_base = 0;
+    long of_shard_stride = 0;
 };
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
 
 // Pair path (pair.hip): two adjacent channels per complex transform, straight from / to interleaved
 // FLOAT_LE frames; fp32, even channel count, 512 <= L <= 8192.  `plan` is the plan of 2L points.
 bool pair_supported(int filter_length);
+// k_fwd / k_inv can take both channels of a stereo float-frame block in one workgroup (direct mode, whole frames)
+bool direct_stereo_supported(int filter_length, int realsize);
 struct FwdPairArgs {
     const float *raw; long eng_stride; long frame_off;   // input frames; engine stride in floats
     int C, n_eng, n_t;
@@ -160,6 +198,10 @@ struct InvPairArgs {
     int C, n_eng, n_t;
     float scale, max;
     DevOverflow *overflow; int *bad_block; int block_base;
+    long of_shard_stride = 0;
+#ifdef BFIR_EXPERIMENT_ALIAS
+    int y_alias = 1 << 30;
+#endif
 };
 void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a, hipStream_t s);
 

@@ -131,30 +131,61 @@ void fft_plan_destroy(FftPlan *plan)
 __device__ __forceinline__ unsigned int abs_bits(float v) { return __float_as_uint(fabsf(v)); }
 __device__ __forceinline__ unsigned long long abs_bits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
+// Two channels per workgroup (k_fwd / k_inv, CPW = 2): both LDS buffers must fit a CU and the workgroup 1024 threads.
+template <typename T, int LOG2M> constexpr bool direct_stereo_fits()
+{
+    return FftCfg<LOG2M>::NT >= 64 && 2 * FftCfg<LOG2M>::NT <= 1024 &&
+           2 * sizeof(T) * 2 * ((size_t(1) << LOG2M) + (size_t(1) << LOG2M) / 32) <= 128 * 1024;
+}
+bool direct_stereo_supported(int filter_length, int realsize)
+{
+    int lg = 0;
+    while ((1 << lg) < filter_length) lg++;
+    bool ok = false;
+    switch (lg) {
+#define F(lg_) case lg_: ok = realsize == 4 ? direct_stereo_fits<float, lg_>() : direct_stereo_fits<double, lg_>(); break;
+        BFIR_FOR_LOG2M(F)
+#undef F
+    }
+    return ok;
+}
+// float frames of a stereo engine whose blocks start on 16-byte boundaries
+static bool direct_stereo_ok(int raw_bytes, int C, const void *raw, long eng_stride_samples, long frame_off)
+{
+    return raw_bytes == 4 && C == 2 && ((uintptr_t)raw % 16) == 0 && (eng_stride_samples % 4) == 0 && (frame_off % 2) == 0;
+}
+
 // ---------------------------------------------------------------------------
 // a6 + a7: forward real FFT into the grouped layout
 // ---------------------------------------------------------------------------
-// TR: type of the raw samples in direct mode (FwdArgs.raw_bytes), void for the planar source
-template <typename T, int LOG2M, bool ILV, typename TR = void>
-__global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
-                                                           const typename Vec2<T>::type *__restrict__ tw,
-                                                           const typename Vec2<T>::type *__restrict__ ws)
+// TR: type of the raw samples in direct mode (FwdArgs.raw_bytes), void for the planar source.
+// CPW = 2 (direct mode, float frames of stereo engines): one workgroup of 2 NT threads transforms BOTH channels
+// of a block, each half in its own LDS buffer, so that the interleaved frames are moved 16 bytes per lane (two
+// whole frames) instead of 4 bytes at a stride.
+template <typename T, int LOG2M, bool ILV, typename TR = void, int CPW = 1>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
+                                                                 const typename Vec2<T>::type *__restrict__ tw,
+                                                                 const typename Vec2<T>::type *__restrict__ ws)
 {
     using F = LdsFft<T, LOG2M, -1>;
     using V2 = typename Vec2<T>::type;
     using V4 = typename Vec4<T>::type;
     constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
-    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) V2 lds_all[CPW][F::LDS_ELEMS];
 
-    const int tid = threadIdx.x;
     constexpr bool DIRECT = !std::is_void<TR>::value;
+    static_assert(CPW == 1 || (CPW == 2 && DIRECT && std::is_same<TR, float>::value), "two channels per workgroup: stereo float frames");
+    const int half = CPW == 1 ? 0 : (int)threadIdx.x / NT;         // which channel of the frame (wave-uniform: NT >= 64)
+    const int tid = CPW == 1 ? (int)threadIdx.x : (int)threadIdx.x - half * NT;
+    V2 *lds = lds_all[half];
     // direct mode: the channels of a block share input cache lines -> give every XCD a contiguous range
     int wi = blockIdx.x;
     if constexpr (DIRECT) {
         const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
         wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
     }
-    const int t = wi / a.n_ch, gc = wi - t * a.n_ch;
+    const int ncw = a.n_ch / CPW;
+    const int t = wi / ncw, gc = (wi - t * ncw) * CPW + half;
     const T *__restrict__ cur = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * M;
     const T *__restrict__ old = (t == 0) ? (const T *)a.prev + (long)gc * a.prev_ch_stride : cur - M;
     T *__restrict__ dst =
@@ -164,7 +195,29 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_fwd(FwdArgs a,
     // z[m] = x[2m] + i x[2m+1] over the window [previous block | this block]
     T re[P], im[P];
     const T ls = (T)a.load_scale;
-    if constexpr (DIRECT) {
+    if constexpr (DIRECT && CPW == 2) {
+        // stereo float frames: float4 m of a block = frames 2m, 2m+1 = (l, r, l, r); a.C == 2, 16-byte aligned (launcher)
+        const int g = gc >> 1;
+        const long ho = (long)g * a.hist_eng_stride;
+        const float4 *__restrict__ rc4 = (const float4 *)((const float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
+        const float4 *__restrict__ ro4 = (t == 0) ? (const float4 *)((const float *)a.prev_raw + ho) : rc4 - M / 2;
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int m = F::in_index(tid, e);
+            if (m < M / 2) {                                   // frames 2m, 2m+1 of the previous block
+                const float4 v = ro4[m];
+                re[e] = (T)(half ? v.y : v.x) * ls; im[e] = (T)(half ? v.w : v.z) * ls;
+                if (a.n_t == 1 && half == 0)                   // one-block chunk: the other history block moves on unchanged
+                    ((float4 *)((float *)a.save_prev + ho))[m] = ((const float4 *)((const float *)a.carry + ho))[m];
+            } else {                                           // frames of this block
+                const float4 v = rc4[m - M / 2];
+                re[e] = (T)(half ? v.y : v.x) * ls; im[e] = (T)(half ? v.w : v.z) * ls;
+                // the engine's history: raw frames of the last two blocks of the chunk (whole frames: one half stores)
+                if (t >= a.n_t - 2 && half == 0)
+                    ((float4 *)((float *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho))[m - M / 2] = v;
+            }
+        }
+    } else if constexpr (DIRECT) {
         using RS = typename std::conditional<DIRECT, TR, float>::type;
         const int C = a.C, g = gc / C, c = gc - g * C;
         const long ho = (long)g * a.hist_eng_stride + c;
@@ -265,6 +318,13 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
     {
         if (a.raw_bytes) {           // direct mode: raw float / double frames in
             const bool il = sizeof(T) == 4 && a.interleaved;
+            if constexpr (direct_stereo_fits<T, LOG2M>()) {
+                if (direct_stereo_ok(a.raw_bytes, a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
+                    hipLaunchKernelGGL((k_fwd<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                       (const V2 *)plan.tw, (const V2 *)plan.ws);
+                    return;
+                }
+            }
 #define BFIR_LAUNCH_FWD_RAW(IL_, TR_) hipLaunchKernelGGL((k_fwd<T, LOG2M, IL_, TR_>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const V2 *)plan.tw, (const V2 *)plan.ws)
             if constexpr (sizeof(T) == 4) {
                 if (il) { if (a.raw_bytes == 4) BFIR_LAUNCH_FWD_RAW(true, float); else BFIR_LAUNCH_FWD_RAW(true, double); return; }
@@ -303,25 +363,31 @@ void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // a11 + a12: inverse real FFT from the grouped layout, valid half only
 // ---------------------------------------------------------------------------
-template <typename T, int LOG2M, bool ILV, typename TR = void>
-__global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
-                                                           const typename Vec2<T>::type *__restrict__ tw,
-                                                           const typename Vec2<T>::type *__restrict__ ws)
+// CPW = 2: both channels of a stereo float-frame block in one workgroup (see k_fwd); the two valid halves meet
+// in LDS as whole frames and leave 16 bytes per lane.
+template <typename T, int LOG2M, bool ILV, typename TR = void, int CPW = 1>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
+                                                                 const typename Vec2<T>::type *__restrict__ tw,
+                                                                 const typename Vec2<T>::type *__restrict__ ws)
 {
     using F = LdsFft<T, LOG2M, +1>;
     using V2 = typename Vec2<T>::type;
     using V4 = typename Vec4<T>::type;
     constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
-    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) V2 lds_all[CPW][F::LDS_ELEMS];
 
-    const int tid = threadIdx.x;
     constexpr bool DIRECT = !std::is_void<TR>::value;
+    static_assert(CPW == 1 || (CPW == 2 && DIRECT && std::is_same<TR, float>::value), "two channels per workgroup: stereo float frames");
+    const int half = CPW == 1 ? 0 : (int)threadIdx.x / NT;
+    const int tid = CPW == 1 ? (int)threadIdx.x : (int)threadIdx.x - half * NT;
+    V2 *lds = lds_all[half];
     int wi = blockIdx.x;
     if constexpr (DIRECT) {       // the channels of a block write the same cache lines: one XCD
         const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
         wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
     }
-    const int t = wi / a.n_ch, gc = wi - t * a.n_ch;
+    const int ncw = a.n_ch / CPW;
+    const int t = wi / ncw, gc = (wi - t * ncw) * CPW + half;
     const T *__restrict__ src = (const T *)a.src + (long)gc * a.src_ch_stride + (long)t * N;
     T *__restrict__ dst =
         (T *)a.dst + (long)gc * a.dst_ch_stride + (long)t * (a.full_output ? N : M);
@@ -366,10 +432,16 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
         // valid half -> raw output frames of this channel, with real2raw's bookkeeping
         using RS = typename std::conditional<DIRECT, TR, float>::type;
         using Bits = decltype(abs_bits((T)0));
-        __shared__ Bits red_max[NT / 64 > 0 ? NT / 64 : 1];
-        __shared__ unsigned int red_cnt[NT / 64 > 0 ? NT / 64 : 1];
+        __shared__ Bits red_max_all[CPW][NT / 64 > 0 ? NT / 64 : 1];
+        __shared__ unsigned int red_cnt_all[CPW][NT / 64 > 0 ? NT / 64 : 1];
+        Bits *red_max = red_max_all[half];
+        unsigned int *red_cnt = red_cnt_all[half];
         const int C = a.C, g = gc / C, c = gc - g * C;
         RS *__restrict__ out = (RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c;
+        // CPW = 2: the frames are assembled in the first LDS buffer (2 M floats <= its size), which the other
+        // half's waves may still be reading for their last pass
+        float *stg = (float *)lds_all[0];
+        if constexpr (CPW == 2) __syncthreads();
         const T rmax = (T)a.max, rmin = (T)(-a.max);
         Bits mx = 0; unsigned int cnt = 0u;
 #pragma unroll
@@ -377,7 +449,8 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
             const int m = F::out_index(tid, e);
             if (m < M / 2) {
                 const T v0 = re[e], v1 = im[e];
-                out[(long)(2 * m) * C] = (RS)v0; out[(long)(2 * m + 1) * C] = (RS)v1;
+                if constexpr (CPW == 2) { stg[4 * m + half] = (float)v0; stg[4 * m + 2 + half] = (float)v1; }
+                else { out[(long)(2 * m) * C] = (RS)v0; out[(long)(2 * m + 1) * C] = (RS)v1; }
                 // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
                 cnt += ((v0 < (T)0) ? (v0 < rmin) : (v0 > rmax)) ? 1u : 0u;
                 cnt += ((v1 < (T)0) ? (v1 < rmin) : (v1 > rmax)) ? 1u : 0u;
@@ -395,10 +468,19 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT) void k_inv(InvArgs a,
         }
         if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_cnt[tid >> 6] = cnt; }
         __syncthreads();
+        if constexpr (CPW == 2) {                              // whole frames out: 2 M floats, 16 bytes per lane
+            float4 *__restrict__ out4 = (float4 *)((float *)a.raw + (long)(gc >> 1) * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
+            const float4 *stg4 = (const float4 *)stg;
+#pragma unroll
+            for (int j = 0; j < P / 4; j++) {
+                const int idx = (int)threadIdx.x + j * 2 * NT;
+                out4[idx] = stg4[idx];
+            }
+        }
         if (tid == 0) {
             Bits m2 = 0; unsigned int n2 = 0u;
             for (int wv = 0; wv < (NT + 63) / 64; wv++) { m2 = red_max[wv] > m2 ? red_max[wv] : m2; n2 += red_cnt[wv]; }
-            DevOverflow *of = a.overflow + gc;
+            DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + gc;
             if (n2) atomicAdd(&of->n_overflows, n2);
             if ((unsigned long long)m2 > *(volatile unsigned long long *)&of->largest_bits)
                 atomicMax(&of->largest_bits, (unsigned long long)m2);
@@ -423,6 +505,13 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
     {
         if (a.raw_bytes) {           // direct mode: raw float / double frames out
             const bool il = sizeof(T) == 4 && a.interleaved;
+            if constexpr (direct_stereo_fits<T, LOG2M>()) {
+                if (direct_stereo_ok(a.raw_bytes, a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
+                    hipLaunchKernelGGL((k_inv<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                       (const V2 *)plan.tw, (const V2 *)plan.ws);
+                    return;
+                }
+            }
 #define BFIR_LAUNCH_INV_RAW(IL_, TR_) hipLaunchKernelGGL((k_inv<T, LOG2M, IL_, TR_>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const V2 *)plan.tw, (const V2 *)plan.ws)
             if constexpr (sizeof(T) == 4) {
                 if (il) { if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RAW(true, float); else BFIR_LAUNCH_INV_RAW(true, double); return; }
@@ -1001,11 +1090,139 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds_d2(MacArgs a, int nbt, int n
     }
 }
 
+// The same kernel with G partition steps per barrier.  k_mac_lds_d2 meets at a workgroup barrier after every
+// partition (64 double FMAs per lane, ~0.3 us): at two waves per SIMD the barrier wait is a third of its time.
+// Here the four duty waves publish the operands of G steps at a time (H_s into a 2G-deep buffer, X[tb - s] into
+// the ring: an entry is overwritten 8 steps after its last reader, so up to 4 steps ahead is safe) and the
+// workgroup meets once per G steps.  Same sums in the same order: bit-identical results.
+template <int G, bool DCNY>
+__device__ __forceinline__ void mac_lds_steps_d2g(v2d (&accr)[8], v2d (&acci)[8], double (&dc)[8], double (&ny)[8],
+                                                  v2d (&wr)[8], v2d (&wi)[8], v2d (*s_ring)[2][64], v2d (*s_h)[2][64],
+                                                  const v2d *__restrict__ dbase, long duty_slot, bool duty_is_h,
+                                                  int nb, int ring, int sl_tb, int lane, int wv, int duty_plane)
+{
+    static_assert(G == 2 || G == 4, "G divides the window period 8; ring entries live 8 steps");
+    constexpr int NH = 2 * G;
+    // duty: this wave fetches one plane (re or im; dbase already points at it) of H_s (waves 0, 1) or of
+    // X[tb - s] (waves 2, 3) for every step s, one group of G steps ahead of its use
+    v2d q[G];
+    int dnext = duty_is_h ? 0 : sl_tb;             // operand index of the step whose load comes next
+    auto duty_load = [&]() -> v2d {
+        const v2d v = dbase[dnext * duty_slot];
+        if (duty_is_h) { if (dnext < nb - 1) dnext += 1; }
+        else { dnext -= 1; if (dnext < 0) dnext += ring; }
+        return v;
+    };
+    auto duty_store = [&](int s_, v2d v_) {
+        // X[tb - 0] is the tile's own first block: already in the ring
+        if (duty_is_h) s_h[s_ % NH][duty_plane][lane] = v_;
+        else if (s_ > 0) s_ring[(-s_) & 31][duty_plane][lane] = v_;
+    };
+    // the ring entries these first stores reuse (31, 30, ..) are being filled with the tile's own blocks by
+    // wave 3 right now: every wave's fill first
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < G; u++) { const v2d v = duty_load(); duty_store(u, v); }     // steps 0 .. G-1
+#pragma unroll
+    for (int u = 0; u < G; u++) q[u] = duty_load();                                   // steps G .. 2G-1
+    __syncthreads();
+    for (int i0 = 0; i0 < nb; i0 += 8) {
+#pragma unroll
+        for (int gi = 0; gi < 8 / G; gi++) {
+            if (i0 + gi * G < nb) {   // uniform over the workgroup
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    const int ii = gi * G + u, i = i0 + ii;
+                    if (i < nb) {     // uniform
+                        const v2d hr = s_h[ii % NH][0][lane], hi = s_h[ii % NH][1][lane];
+                        if (i > 0) {
+                            const int e = (8 * wv - i) & 31;             // ring entry holding X[tb + 8 wv - i]
+                            wr[(8 - ii) % 8] = s_ring[e][0][lane]; wi[(8 - ii) % 8] = s_ring[e][1][lane];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int idx = (j - ii + 8) % 8;            // window slot holding X[t0 + j - i]
+                            cmac2d(accr[j], acci[j], wr[idx], wi[idx], hr, hi);
+                            if constexpr (DCNY) {
+                                dc[j] = fma(wr[idx].x, hr.x, dc[j]);
+                                ny[j] = fma(wi[idx].x, hi.x, ny[j]);
+                            }
+                        }
+                    }
+                }
+                // publish the operands of the next G steps, refill the queue with those of the G after them
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    duty_store(i0 + gi * G + G + u, q[u]);
+                    q[u] = duty_load();
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void k_mac_lds_d2g(MacArgs a, int nbt, int nTQ)
+{
+    __shared__ __attribute__((aligned(16))) v2d s_ring[32][2][64];
+    __shared__ __attribute__((aligned(16))) v2d s_h[2 * G][2][64];
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / nTQ, tq = w - s * nTQ;
+    const int gc = s / nbt, bt = s - gc * nbt;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = bt * 32 + (lane >> 1), hh = lane & 1;              // group of 4 bins, which half of it
+    const int tb = tq * 32, t0 = tb + 8 * wv;
+    const long slot = a.N / 2;                                        // v2d elements per spectrum
+    // grouped layout: group g = doubles 8g .. 8g+7 = re0 re1 | re2 re3 | im0 im1 | im2 im3 as four v2d
+    const v2d *__restrict__ X = (const v2d *)((const double *)a.x + (long)gc * a.x_ch_stride) + 4 * g + hh;
+    const v2d *__restrict__ H = (const v2d *)((const double *)a.h + (long)gc * a.h_ch_stride) + 4 * g + hh;
+    const int nb = a.nblk[gc];
+    const int ring = a.ring;
+    const int sl_tb = (a.base_slot + tb) % ring;   // delay-line slot of block tb
+    v2d accr[8], acci[8], wr[8], wi[8];
+    double dc[8], ny[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        accr[j] = v2d{0, 0}; acci[j] = v2d{0, 0};
+        dc[j] = 0.0; ny[j] = 0.0;
+        int sj = sl_tb + 8 * wv + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[sj * slot]; wi[j] = X[sj * slot + 2];
+        s_ring[8 * wv + j][0][lane] = wr[j]; s_ring[8 * wv + j][1][lane] = wi[j];
+    }
+    const bool duty_is_h = wv < 2;
+    const int plane = wv & 1;
+    const v2d *dbase = (duty_is_h ? H : X) + 2 * plane;
+    if (bt == 0)   // lane 0 of this tile holds bin 0: DC in the real slot, Nyquist in the imaginary one
+        mac_lds_steps_d2g<G, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+    else
+        mac_lds_steps_d2g<G, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+    double *__restrict__ Y = (double *)a.y + (long)gc * a.y_ch_stride;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) {
+            if (g == 0 && hh == 0) { accr[j].x = dc[j]; acci[j].x = ny[j]; }
+            v2d *yo = (v2d *)(Y + (long)t * a.N) + 4 * g + hh;
+            yo[0] = accr[j]; yo[2] = acci[j];
+        }
+    }
+}
+
 template <int D> static void launch_mac_lds_d2(const MacArgs &a, hipStream_t s)
 {
     const int nbt = a.N / 8 / 32;              // bin tiles of 32 groups (two lanes per group)
     const int nTQ = (a.n_t + 31) / 32;         // time tiles of 32 blocks
     hipLaunchKernelGGL((k_mac_lds_d2<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+}
+
+template <int G> static void launch_mac_lds_d2g(const MacArgs &a, hipStream_t s)
+{
+    const int nbt = a.N / 8 / 32;
+    const int nTQ = (a.n_t + 31) / 32;
+    hipLaunchKernelGGL((k_mac_lds_d2g<G>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
 }
 
 template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
@@ -1040,19 +1257,40 @@ template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
 
 // ACC (partition batches after the first, B > PB): the sums continue from the partial results the
 // previous batch left in Y; those are fetched D blocks ahead like the spectra (yq, ty_next).
+__device__ __forceinline__ float2 mac_ld_x(const float2 *p)
+{
+#if BFIR_NT_X & 2
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v v = __builtin_nontemporal_load((const f2v *)p);
+    float2 r; r.x = v.x; r.y = v.y; return r;
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void mac_st_y(float2 *p, float2 v)
+{
+#if BFIR_NT_Y & 1
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, (f2v *)p);
+#else
+    *p = v;
+#endif
+}
+
 template <int PB, int D, int MODE, bool ACC>
 __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB], const float (&hr)[PB],
                                                  const float (&hi)[PB], float2 (&q)[D], float2 (&yq)[ACC ? D : 1],
                                                  const float2 *__restrict__ Xc, float2 *__restrict__ Yc, unsigned k,
                                                  int N2, int ring, int &sq, int &ty_next, int tg, int n_t,
-                                                 bool store_lane)
+                                                 bool store_lane, const MacArgs &a)
 {
     static_assert(PB % D == 0, "queue depth must divide the group");
     constexpr int NU = MODE == 2 ? PB - 1 : PB;          // the block PB before the range feeds nothing
     static_for<0, NU>([&](auto U) {                      // spectrum of block t = tg + PB-1-u
         constexpr int u = decltype(U)::value;
         const float xr = q[u % D].x, xi = q[u % D].y;
-        q[u % D] = (Xc + (long)sq * N2)[k];              // uniform base + 32-bit lane offset, 8 bytes per lane
+        q[u % D] = mac_ld_x(Xc + (long)sq * N2 + k);     // uniform base + 32-bit lane offset, 8 bytes per lane
         sq -= 1; if (sq < 0) sq += ring;
         const float nxi = -xi;
         constexpr int plo = MODE == 2 ? u + 1 : 0, phi = MODE == 0 ? u : PB - 1;
@@ -1083,7 +1321,7 @@ __device__ __forceinline__ void mac_stream_group(float (&ar)[PB], float (&ai)[PB
             const int ty = tg + 2 * PB - 2 - u;
             if (ty < n_t && store_lane) {
                 float2 v; v.x = ar[sl]; v.y = ai[sl];
-                (Yc + (long)ty * N2)[k] = v;
+                mac_st_y(Yc + (long)BFIR_YSLOT(a, ty) * N2 + k, v);
             }
         }
     });
@@ -1152,7 +1390,7 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int 
     int sq = ((a.base_slot + ta + R - 1 - p0) % ring + ring) % ring;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        q[d] = (Xc + (long)sq * N2)[k];
+        q[d] = mac_ld_x(Xc + (long)sq * N2 + k);
         sq -= 1; if (sq < 0) sq += ring;
     }
     float hr[PB], hi[PB];
@@ -1178,21 +1416,26 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void k_mac_stream(MacArgs a, int 
     const bool store_lane = k != 0;
     int tg = ta + R - PB;
     BFIR_STAMP(2, 1);
-    mac_stream_group<PB, D, 0, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 0, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane, a);
     BFIR_STAMP(2, 2);
     for (int g = my_grp - 2; g >= 0; g--) {
         tg -= PB;
-        mac_stream_group<PB, D, 1, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
+        mac_stream_group<PB, D, 1, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane, a);
     }
     BFIR_STAMP(2, 3);
     tg -= PB;
-    mac_stream_group<PB, D, 2, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane);
+    mac_stream_group<PB, D, 2, ACC>(ar, ai, hr, hi, q, yq, Xc, Yc, k, N2, ring, sq, ty_next, tg, a.n_t, store_lane, a);
     BFIR_STAMP(2, 4);
 }
 
 // ngrp: groups of PB blocks per wave (BFIR_MAC_RANGE overrides, in blocks)
-template <int PB, int D> static void launch_mac_stream(const MacArgs &a, hipStream_t s)
+template <int PB, int D> static void launch_mac_stream(const MacArgs &a_, hipStream_t s)
 {
+    MacArgs a = a_;
+#ifdef BFIR_EXPERIMENT_ALIAS
+    if (const int xa = bfir_alias_env("BFIR_X_ALIAS")) { a.ring = xa; a.base_slot %= xa; }
+    if (const int ya = bfir_alias_env("BFIR_Y_ALIAS")) a.y_alias = ya;
+#endif
     // read per launch (a getenv is nanoseconds next to a launch) so tests can switch it in-process
     const char *re_ = getenv("BFIR_MAC_RANGE");
     const int range_env = re_ ? atoi(re_) : 0;
@@ -1281,7 +1524,9 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
         const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid, read per launch
-        if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2<2>(a, s);      // two bins per lane, 32-block tiles
+        if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2g<2>(a, s);     // two bins per lane, 32-block tiles, two partitions per barrier
+        else if (a.N >= 512 && tt >= 32 && v64 == 7) launch_mac_lds_d2<2>(a, s);      // ... a barrier per partition
+        else if (a.N >= 512 && tt >= 32 && v64 == 8) launch_mac_lds_d2g<4>(a, s);     // ... four partitions per barrier
         else if (a.N >= 512 && tt >= 32 && v64 == 4) launch_mac_lds_d2<4>(a, s);
         else if (a.N >= 512 && tt >= 32 && v64 == 5) launch_mac_lds_d2<1>(a, s);
         else if (a.N >= 512 && tt >= 16 && (v64 == 0 || v64 == 6)) launch_mac_lds_d<2>(a, s);
@@ -1479,7 +1724,7 @@ template <typename T, typename TR, int WB> __global__ __launch_bounds__(STAGE_TH
         Bits m = 0;
         unsigned int n = 0u;
         for (int w = 0; w < STAGE_THREADS / 64; w++) { m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; }
-        DevOverflow *of = a.overflow + (e * C + tid);
+        DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + (e * C + tid);
         if (n) atomicAdd(&of->n_overflows, n);
         if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
             atomicMax(&of->largest_bits, (unsigned long long)m);
@@ -1573,7 +1818,7 @@ template <typename T> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_o
         for (int w = 0; w < STAGE_THREADS / 64; w++) {
             m = red_max[w][tid] > m ? red_max[w][tid] : m; n += red_cnt[w][tid]; im = red_int[w][tid] > im ? red_int[w][tid] : im;
         }
-        DevOverflow *of = a.overflow + (e * C + tid);
+        DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + (e * C + tid);
         if (n) atomicAdd(&of->n_overflows, n);
         if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
             atomicMax(&of->largest_bits, (unsigned long long)m);

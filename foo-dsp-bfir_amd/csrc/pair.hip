@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
     if (tid < 2) {
         unsigned int m = 0u, n = 0u;
         for (int wv = 0; wv < (NT + 63) / 64; wv++) { m = red_max[wv][tid] > m ? red_max[wv][tid] : m; n += red_cnt[wv][tid]; }
-        DevOverflow *of = a.overflow + (gc + tid);
+        DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + (gc + tid);
         if (n) atomicAdd(&of->n_overflows, n);
         // filtered: the peak only ever grows, a stale read costs an extra atomic, never a wrong result
         if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
@@ -234,11 +234,12 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned v
     float2 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y);
     return f;
 }
+template <int AUX = 0>   // cache policy bits of the instruction: 2 = nt
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 f)
 {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     u4 v; v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
 }
 __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 f)
 {
@@ -286,15 +287,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void asm_prefetch2x4x4(u32x4 (&a)[4], u32x4 (&b)[4], unsigned voff, i32x4 ra, i32x4 rb, unsigned step)
 {
     const unsigned s1 = __builtin_amdgcn_readfirstlane(step), s2 = 2 * s1, s3 = 3 * s1;
+#if BFIR_NT_Y & 2
+#define BFIR_YLD_POLICY " nt"
+#else
+#define BFIR_YLD_POLICY ""
+#endif
     asm volatile("s_nop 4\n\t"
-                 "buffer_load_dwordx4 %0, %8, %9, 0 offen\n\t"
-                 "buffer_load_dwordx4 %4, %8, %10, 0 offen\n\t"
-                 "buffer_load_dwordx4 %1, %8, %9, %11 offen\n\t"
-                 "buffer_load_dwordx4 %5, %8, %10, %11 offen\n\t"
-                 "buffer_load_dwordx4 %2, %8, %9, %12 offen\n\t"
-                 "buffer_load_dwordx4 %6, %8, %10, %12 offen\n\t"
-                 "buffer_load_dwordx4 %3, %8, %9, %13 offen\n\t"
-                 "buffer_load_dwordx4 %7, %8, %10, %13 offen"
+                 "buffer_load_dwordx4 %0, %8, %9, 0 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %4, %8, %10, 0 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %1, %8, %9, %11 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %5, %8, %10, %11 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %2, %8, %9, %12 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %6, %8, %10, %12 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %3, %8, %9, %13 offen" BFIR_YLD_POLICY "\n\t"
+                 "buffer_load_dwordx4 %7, %8, %10, %13 offen" BFIR_YLD_POLICY
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
                  : "v"(voff), "s"(ra), "s"(rb), "s"(s1), "s"(s2), "s"(s3)
                  : "memory");
@@ -321,13 +327,18 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
     using F = LdsFft<float, LOG2N, -1>;
     constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, H = P / 2;   // H points per thread and block
     static_assert(F::radix(0) == 16 && P == 16, "in_index(tid, e) = tid + e * (N / 16)");
-    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
+    static_assert(F::phys(32) == 33 && F::phys(N - 1) == N - 1 + N / 32 - 1, "the split step's addresses assume i + (i >> 5)");
+    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS + 1];   // + 1: see the split step
     __shared__ __attribute__((aligned(16))) float2 ldsb[F::LDSB_ELEMS];
 
     const int tid = threadIdx.x;
     const int w = xcd_remap();
     const int half_c = a.C / 2, pairs = a.n_eng * half_c;
     const int rr = w / pairs, pp = w - rr * pairs;                       // run, pair: the pairs of a run share an XCD
+    // The two-for-one split halves every sum (Xa = (Z[k] + conj Z[N-k]) / 2 ...): the half goes into the input
+    // scale instead, which is exact (a power of two commutes with every rounding of the transform), and
+    // the two purely real bins, which the split takes unhalved, are doubled back (exact again).
+    const float sc = 0.5f * a.scale;
     const int g = pp / half_c, cp = pp - g * half_c;
     const int C = a.C;
     const int t0 = rr * run_len, t1 = min(a.n_t, t0 + run_len);
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
 #pragma unroll
         for (int e = 0; e < H; e++) {
             const float2 v = buf_load2(ro, fo, e * estep);
-            cur[e].x = v.x * a.scale; cur[e].y = v.y * a.scale;
+            cur[e].x = v.x * sc; cur[e].y = v.y * sc;
         }
         if (a.n_t == 1) {                                                // one-block chunk: the other history block moves on unchanged
             const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.carry + hist, blk_bytes), rp = make_rsrc(a.save_prev + hist, blk_bytes);
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
         for (int e = 0; e < H; e++) {
             float2 v; v.x = __uint_as_float(nxt[e].x); v.y = __uint_as_float(nxt[e].y);   // raw frames of block t
             re[e] = cur[e].x; im[e] = cur[e].y;                          // window = [block t-1 | block t]
-            cur[e].x = v.x * a.scale; cur[e].y = v.y * a.scale;
+            cur[e].x = v.x * sc; cur[e].y = v.y * sc;
             re[H + e] = cur[e].x; im[H + e] = cur[e].y;
         }
         {
@@ -402,13 +413,18 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
             }
         });
 
-        // Z in natural order to LDS, then two-for-one split
+        // Z in natural order to LDS, then two-for-one split.  Every LDS address below is one per-thread base
+        // plus a compile-time offset (i + (i >> 5) is additive for offsets that are multiples of 32).
         int tz = tid; asm volatile("" : "+v"(tz));
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < P; e++) {
-            float2 v; v.x = re[e]; v.y = im[e];
-            lds[F::phys(F::out_index(tz, e))] = v;
+        {
+            float2 *zw = lds + F::phys(tz);
+            static_for<0, P>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                static_assert(F::out_index(0, e) % 32 == 0, "additive padding");
+                float2 v; v.x = re[e]; v.y = im[e];
+                zw[F::phys(F::out_index(0, e))] = v;
+            });
         }
         __syncthreads();
         const long slot = (long)((a.base_slot + t) % a.ring) * N;
@@ -416,26 +432,35 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
         // A thread splits two ADJACENT bins (k = 2 m, 2 m + 1; m = tid + j NT) so that each spectrum store is
         // 16 bytes per lane: vector stores are issue-bound per instruction on this chip (8-byte stores run at
         // about 7 B/clk/CU, MI355X_MICROARCH.md cycle table), and this kernel stores twice what it loads.
+        // Z[k], Z[k+1] sit at zk[phys(2 NT j)], + 1.  Z[N-k-1] sits at zn1[-phys(2 NT j)]: N-1-2 tid has
+        // its low five bits free of borrows; Z[N-k] one element further, two where N-k is a multiple of 32 (a pad
+        // element lies between).  Lane 0 at j = 0 reads Z[N] = lds[LDS_ELEMS], the spare element: its
+        // bin 0 is replaced below.
+        const float2 *zk = lds + F::phys(2 * tz);
+        constexpr int OMAX = F::phys(2 * NT * (P / 4 - 1));              // bases lowered so that every offset is >= 0
+        const float2 *zn1 = lds + (F::phys(N - 1 - 2 * tz) - OMAX);
+        const float2 *zn0 = zn1 + ((tz & 15) == 0 ? 2 : 1);
 #pragma unroll
         for (int j = 0; j < P / 4; j++) {
             // one pair at a time: left alone the scheduler fetches all sixteen Z values first (32 registers
             // on top of the prefetch and the carried block)
             if (j > 0) __builtin_amdgcn_sched_barrier(0);
-            const int m = tz + j * NT, k = 2 * m;
-            const float2 zk0 = lds[F::phys(k)], zk1 = lds[F::phys(k + 1)];
-            const float2 zn0 = lds[F::phys((N - k) & (N - 1))], zn1 = lds[F::phys(N - k - 1)];
+            const int o = F::phys(2 * NT * j);
+            const float2 zk0 = zk[o], zk1 = zk[o + 1];
+            const float2 zn0v = zn0[OMAX - o], zn1v = zn1[OMAX - o];
             float4 xa, xb;
-            xa.x = 0.5f * (zk0.x + zn0.x); xa.y = 0.5f * (zk0.y - zn0.y);
-            xb.x = 0.5f * (zk0.y + zn0.y); xb.y = -0.5f * (zk0.x - zn0.x);
-            xa.z = 0.5f * (zk1.x + zn1.x); xa.w = 0.5f * (zk1.y - zn1.y);
-            xb.z = 0.5f * (zk1.y + zn1.y); xb.w = -0.5f * (zk1.x - zn1.x);
+            xa.x = zk0.x + zn0v.x; xa.y = zk0.y - zn0v.y;
+            xb.x = zk0.y + zn0v.y; xb.y = zn0v.x - zk0.x;
+            xa.z = zk1.x + zn1v.x; xa.w = zk1.y - zn1v.y;
+            xb.z = zk1.y + zn1v.y; xb.w = zn1v.x - zk1.x;
             if (j == 0) {                                                // m = tid: bin 0 is DC | Nyquist, both real
                 const float2 zh = lds[F::phys(L)];
                 const bool k0 = tz == 0;
-                xa.x = k0 ? zk0.x : xa.x; xa.y = k0 ? zh.x : xa.y; xb.x = k0 ? zk0.y : xb.x; xb.y = k0 ? zh.y : xb.y;
+                xa.x = k0 ? 2.f * zk0.x : xa.x; xa.y = k0 ? 2.f * zh.x : xa.y;
+                xb.x = k0 ? 2.f * zk0.y : xb.x; xb.y = k0 ? 2.f * zh.y : xb.y;
             }
-            buf_store4(rxa, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xa);
-            buf_store4(rxb, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xb);
+            buf_store4<(BFIR_NT_X & 1) ? 2 : 0>(rxa, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xa);
+            buf_store4<(BFIR_NT_X & 1) ? 2 : 0>(rxb, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xb);
         }
         // the next transform's first exchange starts with a barrier, which also protects these LDS reads
     }
@@ -485,19 +510,23 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
     static_assert(Q == 4, "the prefetch statement moves four 16-byte pieces per thread and spectrum");
     u32x4 qa[Q], qb[Q];
     {
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc(ya0 + (long)t0 * N, (unsigned)N * 4u);
-        const __amdgpu_buffer_rsrc_t rb = make_rsrc(ya0 + a.y_ch_stride + (long)t0 * N, (unsigned)N * 4u);
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(ya0 + (long)BFIR_YSLOT(a, t0) * N, (unsigned)N * 4u);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(ya0 + a.y_ch_stride + (long)BFIR_YSLOT(a, t0) * N, (unsigned)N * 4u);
 #pragma unroll
         for (int j = 0; j < Q; j++) {
-            qa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, 0);
-            qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, 0);
+            qa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, (BFIR_NT_Y & 2) ? 2 : 0);
+            qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, (BFIR_NT_Y & 2) ? 2 : 0);
         }
         // consumed before the loop: inside it the compiler has no pending load of its own (see k_fwd_pair_ps)
 #pragma unroll
         for (int j = 0; j < Q; j++) asm volatile("" : "+v"(qa[j]), "+v"(qb[j]));
     }
-    const float rmax = a.max, rmin = -a.max;
-    unsigned int mx0 = 0u, mx1 = 0u, c0 = 0u, c1 = 0u;
+    // brutefir/real2raw.cpp:321-336 counts v < 0 ? v < -max : v > max (strict, NaN never counts) and tracks the
+    // largest magnitude: with symmetric limits that is |v| > max, and a float maximum that skips NaNs
+    // (fmaxf) -- three instructions per sample instead of twelve.
+    const float rmax = a.max;
+    float pk0 = 0.f, pk1 = 0.f;
+    unsigned int c0 = 0u, c1 = 0u;
     int bad = 0x7fffffff;
     for (int t = t0; t < t1; t++) {
         // both spectra into LDS: Ya at [0, L), Yb at [L, 2L)  (float2 units)
@@ -544,8 +573,8 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
                 // the next block's spectra, under the remaining passes; past the end of the run the descriptors
                 // have zero bytes and the loads return zeros (no branch in the loop, see k_fwd_pair_ps)
                 const unsigned nbytes = t + 1 < t1 ? (unsigned)N * 4u : 0u;
-                asm_prefetch2x4x4(qa, qb, (unsigned)tl * 16u, make_rsrc_words(ya0 + (long)(t + 1) * N, nbytes),
-                                  make_rsrc_words(ya0 + a.y_ch_stride + (long)(t + 1) * N, nbytes), (unsigned)NT * 16u);
+                asm_prefetch2x4x4(qa, qb, (unsigned)tl * 16u, make_rsrc_words(ya0 + (long)BFIR_YSLOT(a, t + 1) * N, nbytes),
+                                  make_rsrc_words(ya0 + a.y_ch_stride + (long)BFIR_YSLOT(a, t + 1) * N, nbytes), (unsigned)NT * 16u);
             }
         });
 
@@ -558,12 +587,9 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
             if (F::out_index(0, e) < L) {                                // compile time: out_index(tid, e) = tid + const, tid < NT <= L
                 float2 v; v.x = re[e]; v.y = im[e];
                 buf_store2(ro, (unsigned)to * (unsigned)C * 4u, (unsigned)F::out_index(0, e) * (unsigned)C * 4u, v);
-                // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
-                c0 += ((v.x < 0.f) ? (v.x < rmin) : (v.x > rmax)) ? 1u : 0u;
-                c1 += ((v.y < 0.f) ? (v.y < rmin) : (v.y > rmax)) ? 1u : 0u;
-                const unsigned int b0 = (v.x == v.x) ? __float_as_uint(fabsf(v.x)) : 0u;
-                const unsigned int b1 = (v.y == v.y) ? __float_as_uint(fabsf(v.y)) : 0u;
-                mx0 = b0 > mx0 ? b0 : mx0; mx1 = b1 > mx1 ? b1 : mx1;
+                c0 += (fabsf(v.x) > rmax) ? 1u : 0u;
+                c1 += (fabsf(v.y) > rmax) ? 1u : 0u;
+                pk0 = fmaxf(pk0, fabsf(v.x)); pk1 = fmaxf(pk1, fabsf(v.y));
                 // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked; the first bad block
                 // of the run is reported once, after the loop (no atomic inside it)
                 if (F::out_index(0, e) == 0) {
@@ -578,6 +604,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
     // late zeros then turn into a null pointer (seen as a sporadic "memory access fault on address (nil)").
     asm_wait_vmcnt<0>(qa, qb);
     if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
+    unsigned int mx0 = __float_as_uint(pk0), mx1 = __float_as_uint(pk1);   // non-negative floats order like their bits
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int m0 = __shfl_xor(mx0, o), m1 = __shfl_xor(mx1, o);
@@ -589,7 +616,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
     if (tid < 2) {
         unsigned int m = 0u, n = 0u;
         for (int wv = 0; wv < (NT + 63) / 64; wv++) { m = red_max[wv][tid] > m ? red_max[wv][tid] : m; n += red_cnt[wv][tid]; }
-        DevOverflow *of = a.overflow + (gc + tid);
+        DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + (gc + tid);
         if (n) atomicAdd(&of->n_overflows, n);
         // filtered: the peak only ever grows, a stale read costs an extra atomic, never a wrong result
         if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
@@ -621,8 +648,12 @@ static int pair_run_len(int n_t, int pairs, bool inverse)
     return std::min(fill, 4);
 }
 
-void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a, hipStream_t s)
+void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a_, hipStream_t s)
 {
+    FwdPairArgs a = a_;
+#ifdef BFIR_EXPERIMENT_ALIAS
+    if (const int xa = bfir_alias_env("BFIR_X_ALIAS")) { a.ring = xa; a.base_slot %= xa; }
+#endif
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
     const char *pe = getenv("BFIR_PAIR_PERSIST");
@@ -643,8 +674,12 @@ void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a, hipStream_t s)
     }
 }
 
-void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a, hipStream_t s)
+void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a_, hipStream_t s)
 {
+    InvPairArgs a = a_;
+#ifdef BFIR_EXPERIMENT_ALIAS
+    if (const int ya = bfir_alias_env("BFIR_Y_ALIAS")) a.y_alias = ya;
+#endif
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
     const char *pe = getenv("BFIR_PAIR_PERSIST");

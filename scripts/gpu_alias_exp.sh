@@ -19,3 +19,6 @@ BFIR_X_ALIAS=128 BFIR_Y_ALIAS=64 run xy_alias
 BFIR_X_ALIAS=128 run x_alias
 BFIR_Y_ALIAS=64 run y_alias
 BFIR_X_ALIAS=1024 BFIR_Y_ALIAS=1024 run xy_alias_1024
+BFIR_X_ALIAS=64 BFIR_Y_ALIAS=32 run xy_alias_64_32
+BFIR_X_ALIAS=256 BFIR_Y_ALIAS=256 run xy_alias_256
+BFIR_X_ALIAS=512 BFIR_Y_ALIAS=512 run xy_alias_512

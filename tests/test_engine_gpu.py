@@ -238,6 +238,7 @@ def test_create_rejects_bad_arguments(bfir):
 
 
 @pytest.mark.parametrize("s,L,B,C,in_fmt,out_fmt", [(8, 1024, 5, 2, 8, 8),     # the plug-in: REALSIZE 8, float32 frames
+                                                   (8, 2048, 3, 2, 8, 8),     # ... both channels in one workgroup
                                                    (8, 256, 3, 3, 10, 10), (4, 256, 4, 3, 8, 8), (4, 16384, 2, 1, 8, 10),
                                                    (8, 4096, 2, 5, 10, 8), (4, 64, 3, 2, 8, 8)])
 def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, in_fmt, out_fmt):
@@ -271,3 +272,42 @@ def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, i
     ref = orc.Engine(L, B, s, C, in_fmt, out_fmt); ref.set_coeff(h, scale=12.0)
     y_ref = ref.run(x)[1]
     assert rel_err(outs[0][0][:nb * L], y_ref) <= (1e-5 if (s == 4 or out_fmt == 8) else 1e-12)
+
+
+@pytest.mark.parametrize("misalign", [0, 8])
+def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
+    """The plug-in's shape (REALSIZE 8, float32 stereo frames) runs k_fwd / k_inv with both channels of a block in
+    one workgroup and 16-byte frame accesses; buffers that are only 8-byte aligned fall back to one channel
+    per workgroup.  Either way: the bits of the staging kernels, for a batch of engines on device buffers."""
+    import os
+    import torch
+    L, B, C, nb, ne = 1024, 4, 2, 9, 3
+    rng = np.random.default_rng(5 + misalign)
+    hs = [orc.synth_ir(rng, C, B * L - 3, np.float64) for _ in range(ne)]
+    x = (orc.synth_audio(rng, ne * nb * L, C, np.float64) * 1.3).astype(np.float32).reshape(ne, nb * L, C)
+    pad = misalign // 4
+    d_x = torch.zeros(x.size + 4, dtype=torch.float32, device="cuda")
+    d_x[pad:pad + x.size] = torch.from_numpy(x.reshape(-1)).cuda()
+    outs = []
+    for direct in (None, "0"):
+        if direct is not None:
+            os.environ["BFIR_DIRECT"] = direct
+        try:
+            eng = bfir.Brutefir(L, B, 8, C, 8, 8, n_engines=ne)
+        finally:
+            os.environ.pop("BFIR_DIRECT", None)
+        eng.set_chunk(4)
+        for g in range(ne):
+            assert eng.set_coeff(hs[g], engine_index=g) == 0
+        d_y = torch.zeros(x.size + 4, dtype=torch.float32, device="cuda")
+        stride = nb * L * C * 4
+        for a, b in ((0, 5), (5, 6), (6, nb)):
+            eng.run_device(d_x.data_ptr() + misalign + a * L * C * 4, d_y.data_ptr() + misalign + a * L * C * 4, b - a,
+                           in_stride_bytes=stride, out_stride_bytes=stride)
+        assert eng.sync() == 0
+        outs.append(d_y[pad:pad + x.size].cpu().numpy().reshape(ne, nb * L, C))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+    for g in range(ne):
+        ref = orc.Engine(L, B, 8, C, 8, 8); ref.set_coeff(hs[g])
+        assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames

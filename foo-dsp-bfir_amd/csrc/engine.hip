@@ -907,6 +907,14 @@ static int ensure_staging(bfir_engine *e, int min_blocks = 0)
 // frames into the other one straight across the host link (a block is a few KiB), launched back to back on
 // one stream; one 4-byte copy brings the NaN verdict; one stream synchronise ends the call.
 static constexpr int kSmallRun = 4;
+
+// 16 bytes per lane between pinned host memory and HBM (whole cache lines across the host link)
+__global__ __launch_bounds__(256) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long n16)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_blocks)
 {
     int rc = ensure_chunk(e, n_blocks);
@@ -917,12 +925,31 @@ static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_bloc
     if (!e->h_bad) { HIP_TRY(hipHostMalloc((void **)&e->h_bad, sizeof(int), hipHostMallocDefault)); }
     const size_t per_in = (size_t)n_blocks * e->L * e->C * e->in_bytes, per_out = (size_t)n_blocks * e->L * e->C * e->out_bytes;
     memcpy(e->pin_in[0], inbuf, per_in * e->n_eng);       // engine after engine, n_blocks * L frames each: same layout
+    // Frames wider than what one workgroup of the fused FFT kernels consumes (a channel pair or one channel of
+    // many): every workgroup would pull its 8 bytes of each frame across the host link on its own (measured:
+    // 26 us per FFT kernel for one block of the 8-channel headline shape, against 8 us for stereo frames).
+    // Those engines get the block into HBM and out of it by a copy kernel moving whole lines: two more
+    // launches, ~35 us less per call.
+    const bool bounce = (e->pair || e->direct) && (size_t)e->C * e->in_bytes > 8 && !getenv("BFIR_NO_BOUNCE");
+    const void *src = e->pin_in[0];
+    void *dst = e->pin_out[0];
+    if (bounce) {
+        const long n16 = (long)(per_in * e->n_eng / 16);
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, e->stream, (uint4 *)e->dev_in[0],
+                           (const uint4 *)e->pin_in[0], n16);
+        src = e->dev_in[0]; dst = e->dev_out[0];
+    }
     e->inline_launch = true;
     for (int c0 = 0; c0 < n_blocks && rc == BFIR_OK; c0 += e->chunk)       // the work buffers hold e->chunk blocks
-        rc = run_chunk(e, e->pin_in[0], (long)per_in, e->pin_out[0], (long)per_out, (long)c0 * e->L,
+        rc = run_chunk(e, src, (long)per_in, dst, (long)per_out, (long)c0 * e->L,
                        std::min(e->chunk, n_blocks - c0), c0, e->stream, nullptr);
     e->inline_launch = false;
     if (rc != BFIR_OK) return rc;
+    if (bounce) {
+        const long n16 = (long)(per_out * e->n_eng / 16);
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, e->stream, (uint4 *)e->pin_out[0],
+                           (const uint4 *)e->dev_out[0], n16);
+    }
     HIP_TRY(hipMemcpyAsync(e->h_bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     drain_spans(e);

@@ -1490,10 +1490,77 @@ static int mac_variant()
     return v;
 }
 
+// ---------------------------------------------------------------------------
+// k_mac_small: the sums of a handful of output blocks (the one-block-per-call latency path)
+// ---------------------------------------------------------------------------
+// One lane owns ONE bin of one output block and runs the reference's chain over the partitions in order
+// (same fma sequence as every other MAC kernel: bit-identical sums), U partitions' operands in flight at a
+// time.  The throughput kernels are built around reuse over many blocks; called for one block they either
+// walk a whole group of history twice (k_mac_stream: 63 spectra for 32 products) or run on two workgroups
+// (k_mac<double>: 30 us for the plug-in's shape, half of the whole call).  Here one block of the plug-in's
+// shape is 8 workgroups of independent loads.
+template <typename T, bool ILV, int U>
+__global__ __launch_bounds__(256) void k_mac_small(MacArgs a)
+{
+    const int N = a.N, N2 = N / 2, ring = a.ring;
+    const int k = blockIdx.x * 256 + threadIdx.x;                 // bin; bin 0 carries DC | Nyquist
+    const int t = blockIdx.y, gc = blockIdx.z;
+    if (k >= N2) return;
+    const T *__restrict__ X = (const T *)a.x + (long)gc * a.x_ch_stride;
+    const T *__restrict__ H = (const T *)a.h + (long)gc * a.h_ch_stride;
+    T *__restrict__ Y = (T *)a.y + (long)gc * a.y_ch_stride + (long)t * N;
+    const int nb = a.nblk[gc];
+    // (re, im) pairs: 2k, 2k+1.  The reference's groups: 4 re then 4 im per 4 bins.
+    const int ore = ILV ? 2 * k : 8 * (k >> 2) + (k & 3), oim = ILV ? ore + 1 : ore + 4;
+    int sl = (a.base_slot + t) % ring;                            // delay-line slot of X[t - p], p = 0
+    T ar = (T)0, ai = (T)0;
+    for (int p0 = 0; p0 < nb; p0 += U) {
+        T xr[U], xi[U], hr[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + u < nb ? p0 + u : nb - 1;          // clamped: in range, never used
+            const T *xs = X + (long)sl * N, *hs = H + (long)p * N;
+            if constexpr (ILV) {
+                using V2 = typename Vec2<T>::type;
+                const V2 xv = *(const V2 *)(xs + ore), hv = *(const V2 *)(hs + ore);
+                xr[u] = xv.x; xi[u] = xv.y; hr[u] = hv.x; hi[u] = hv.y;
+            } else {
+                xr[u] = xs[ore]; xi[u] = xs[oim]; hr[u] = hs[ore]; hi[u] = hs[oim];
+            }
+            sl -= 1; if (sl < 0) sl += ring;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (p0 + u < nb) {
+                if (k == 0) {                                     // two independent real sums
+                    ar = fma(xr[u], hr[u], ar); ai = fma(xi[u], hi[u], ai);
+                } else {
+                    ar = fma(xr[u], hr[u], ar); ar = fma(-xi[u], hi[u], ar);
+                    ai = fma(xr[u], hi[u], ai); ai = fma(xi[u], hr[u], ai);
+                }
+            }
+        }
+    }
+    Y[ore] = ar; Y[oim] = ai;
+}
+
+constexpr int BFIR_MAC_SMALL_MAX = 4;      // output blocks per launch up to which k_mac_small runs (engine.hip: kSmallRun)
+static void launch_mac_small(const MacArgs &a, hipStream_t s)
+{
+    const dim3 grid((a.N / 2 + 255) / 256, a.n_t, a.n_ch), block(256);
+    if (a.realsize == 4) {
+        if (a.interleaved) hipLaunchKernelGGL((k_mac_small<float, true, 16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_mac_small<float, false, 16>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_mac_small<double, false, 16>), grid, block, 0, s, a);
+    }
+}
+
 void launch_mac(const MacArgs &a, hipStream_t s)
 {
     if (a.n_t <= 0 || a.n_ch <= 0) return;
     const int tt = a.n_t;
+    if (tt <= BFIR_MAC_SMALL_MAX && !getenv("BFIR_NO_MAC_SMALL")) { launch_mac_small(a, s); return; }   // env: A/B and tests
     if (a.realsize == 4) {
         const int v = mac_variant();
         // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing experiment: how fast would today's three kernels run if X and Y never left the caches?
-# (library built with -DBFIR_EXPERIMENT_ALIAS folds the delay line / product spectra into a few slots;
-# results are garbage, instruction streams and launch geometry unchanged)
+# (library built with -DBFIR_EXPERIMENT_ALIAS -- _build.build_variant("alias", ["-DBFIR_EXPERIMENT_ALIAS"]) -- folds the
+# delay line / product spectra into a few slots; results are garbage, instruction streams and launch geometry unchanged)
 set -o pipefail
 OUT=gpurun_out/${1:-alias}
 mkdir -p $OUT
@@ -18,7 +18,6 @@ run base
 BFIR_X_ALIAS=128 BFIR_Y_ALIAS=64 run xy_alias
 BFIR_X_ALIAS=128 run x_alias
 BFIR_Y_ALIAS=64 run y_alias
-BFIR_X_ALIAS=1024 BFIR_Y_ALIAS=1024 run xy_alias_1024
 BFIR_X_ALIAS=64 BFIR_Y_ALIAS=32 run xy_alias_64_32
-BFIR_X_ALIAS=256 BFIR_Y_ALIAS=256 run xy_alias_256
 BFIR_X_ALIAS=512 BFIR_Y_ALIAS=512 run xy_alias_512
+run base2

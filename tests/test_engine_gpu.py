@@ -311,3 +311,36 @@ def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
     for g in range(ne):
         ref = orc.Engine(L, B, 8, C, 8, 8); ref.set_coeff(hs[g])
         assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames
+
+
+@pytest.mark.parametrize("s,L,B,C", [(4, 1024, 40, 2), (4, 128, 5, 3), (8, 1024, 7, 2), (4, 4096, 9, 8), (8, 64, 3, 1)])
+def test_small_launch_mac_kernel_gives_the_bits_of_the_throughput_kernels(orc, bfir, s, L, B, C):
+    """Calls of up to four blocks (the plug-in's pattern is one) run k_mac_small -- one lane per bin walking the
+    partitions in order -- and 8-channel engines bounce the block through HBM with a copy kernel.  Same
+    chain of fused multiply-adds as the streaming / LDS / tiled MAC kernels: identical output bits, whether the
+    blocks come one by one, in fours, or all in one launch."""
+    import os
+    nb = 11
+    rng = np.random.default_rng(L + B)
+    h = orc.synth_ir(rng, C, B * L - 5, orc.real_dtype(s))
+    x = orc.synth_audio(rng, nb * L, C, orc.real_dtype(s))
+    outs = []
+    for mode in ("small", "no_small", "one_launch"):
+        if mode == "no_small":
+            os.environ["BFIR_NO_MAC_SMALL"] = "1"; os.environ["BFIR_NO_BOUNCE"] = "1"
+        try:
+            eng = bfir.Brutefir(L, B, s, C)
+            assert eng.set_coeff(h) == 0
+            if mode == "one_launch":
+                eng.set_chunk(16)
+                parts = [eng.run(x)[1]]
+            else:
+                cuts = [0, 1, 2, 4, 8, 9, nb]                       # calls of 1, 1, 2, 4, 1, 2 blocks
+                parts = [eng.run(x[a * L:b * L])[1] for a, b in zip(cuts[:-1], cuts[1:])]
+            outs.append(np.concatenate(parts))
+            eng.close()
+        finally:
+            os.environ.pop("BFIR_NO_MAC_SMALL", None); os.environ.pop("BFIR_NO_BOUNCE", None)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(h)
+    assert rel_err(outs[0], ref.run(x)[1]) <= TOL[s]

@@ -348,11 +348,22 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
     F::load_bases(B, ldsb, twb, tid);                                    // the first exchange's barrier publishes ldsb
 
     // frame n = tid + e NT of a block of frames sits at byte  blk + 4 (e NT C + tid C)  (+ 8 cp for the pair)
+#ifdef BFIR_EXPERIMENT_PLANAR_IO
+    // Timing experiment (profiles/r02_frame_io_experiment.txt): what would whole-line frame I/O be worth?  Each
+    // pair's L x 2 floats of a block are taken from / put to a contiguous eighth... quarter of the block's bytes
+    // (results garbage, byte counts and instruction streams those of the product kernel).
+    const float *__restrict__ raw = a.raw + (long)g * a.eng_stride + a.frame_off * C + (long)cp * L * 2;
+    const long hist = (long)g * a.hist_eng_stride + (long)cp * L * 2;
+    const unsigned blk_bytes = (unsigned)L * 2 * 4u;
+    const unsigned fo = (unsigned)tid * 2u * 4u;
+    const unsigned estep = (unsigned)NT * 2 * 4u;
+#else
     const float *__restrict__ raw = a.raw + (long)g * a.eng_stride + a.frame_off * C + 2 * cp;
     const long hist = (long)g * a.hist_eng_stride + 2 * cp;
     const unsigned blk_bytes = (unsigned)L * C * 4u;
     const unsigned fo = (unsigned)tid * (unsigned)C * 4u;                // lane offset into a block of frames
     const unsigned estep = (unsigned)NT * C * 4u;                        // bytes between a thread's consecutive points
+#endif
     static_assert(H == 8, "the prefetch statement moves eight points per thread");
     float2 cur[H];
     u32x2 nxt[H];                                                        // raw frames of the next block, as loaded
@@ -505,8 +516,15 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
     F::load_bases(B, ldsb, twb, tid);
 
     const float *__restrict__ ya0 = a.y + (long)gc * a.y_ch_stride;
+#ifdef BFIR_EXPERIMENT_PLANAR_IO
+    float *__restrict__ out0 = a.raw + (long)g * a.eng_stride + a.frame_off * C + (long)cp * L * 2;
+    const unsigned blk_bytes = (unsigned)L * 2 * 4u;
+    const unsigned cio = 2u;
+#else
     float *__restrict__ out0 = a.raw + (long)g * a.eng_stride + a.frame_off * C + 2 * cp;
     const unsigned blk_bytes = (unsigned)L * C * 4u;
+    const unsigned cio = (unsigned)C;                                    // floats between a pair's consecutive frames
+#endif
     static_assert(Q == 4, "the prefetch statement moves four 16-byte pieces per thread and spectrum");
     u32x4 qa[Q], qb[Q];
     {
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArg
             const int n = F::out_index(to, e);
             if (F::out_index(0, e) < L) {                                // compile time: out_index(tid, e) = tid + const, tid < NT <= L
                 float2 v; v.x = re[e]; v.y = im[e];
-                buf_store2(ro, (unsigned)to * (unsigned)C * 4u, (unsigned)F::out_index(0, e) * (unsigned)C * 4u, v);
+                buf_store2(ro, (unsigned)to * cio * 4u, (unsigned)F::out_index(0, e) * cio * 4u, v);
                 c0 += (fabsf(v.x) > rmax) ? 1u : 0u;
                 c1 += (fabsf(v.y) > rmax) ? 1u : 0u;
                 pk0 = fmaxf(pk0, fabsf(v.x)); pk1 = fmaxf(pk1, fabsf(v.y));

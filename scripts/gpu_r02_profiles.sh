@@ -63,6 +63,8 @@ PY
 run cfg2 --workload cfg2_2ch_65536tap_L8192_fp32 --blocks 32768
 run cfg4_256streams --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256 --blocks 480
 run cfg5_fp64 --workload cfg5_2ch_262144tap_L4096_fp64 --blocks 16384
+run plugin_fp64_f32frames --workload plugin_2ch_65536tap_L1024_fp64_f32frames --blocks 32768      # the plug-in as shipped
+BFIR_DIRECT=0 run plugin_fp64_f32frames_staging --workload plugin_2ch_65536tap_L1024_fp64_f32frames --blocks 32768
 run plugin_fp64_f64frames --workload plugin_2ch_65536tap_L1024_fp64 --blocks 32768
 run plugin_fp32 --workload plugin_2ch_65536tap_L1024_fp32 --blocks 65536
 run plugin_8ch_B64 --workload plugin_8ch_65536tap_L1024_fp32 --blocks 32768
@@ -70,8 +72,9 @@ run plugin_8ch_B128 --workload plugin_8ch_131072tap_L1024_fp32 --blocks 32768
 BFIR_PAIR=0 run cfg3_staging_path --workload cfg3_8ch_131072tap_L4096_fp32 --blocks 32768
 BFIR_PAIR_PERSIST=0 run cfg3_r01_fft_kernels --workload cfg3_8ch_131072tap_L4096_fp32 --blocks 32768
 echo "== plug-in shape + host path" | tee -a $OUT/progress.log
-timeout -k 10 300 python scripts/plugin_shape.py 2>&1 | grep realsize | tee $OUT/plugin_shape.txt
+for g in 0.01 0.0005; do timeout -k 10 300 python scripts/plugin_shape.py $g 2>&1 | grep realsize; done | tee $OUT/plugin_shape.txt
 timeout -k 10 300 python scripts/host_path.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_path.txt
+bash scripts/gpu_lat_prof.sh $TAG/latprof 2>&1 | grep -v amdgpu.ids | tee $OUT/latency_kernels.txt
 echo "== two ranks on this one GPU (gloo), both sharding modes" | tee -a $OUT/progress.log
 timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --device 0 --blocks 32768 --steps 6 --warmup 2 --no-extras --no-cpu-baseline > $OUT/gpus2_replicas.json 2>$OUT/gpus2.err; python -c "import json; d=json.load(open('$OUT/gpus2_replicas.json')); print('replicas', d['n_gpus'], d['scaling'], d['value'])"
 timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --device 0 --shard channels --blocks 32768 --steps 6 --warmup 2 --no-extras --no-cpu-baseline > $OUT/gpus2_channels.json 2>>$OUT/gpus2.err; python -c "import json; d=json.load(open('$OUT/gpus2_channels.json')); print('channels', d['n_gpus'], d['scaling'], d['value'])"

@@ -1095,17 +1095,20 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds_d2(MacArgs a, int nbt, int n
 // Here the four duty waves publish the operands of G steps at a time (H_s into a 2G-deep buffer, X[tb - s] into
 // the ring: an entry is overwritten 8 steps after its last reader, so up to 4 steps ahead is safe) and the
 // workgroup meets once per G steps.  Same sums in the same order: bit-identical results.
-template <int G, bool DCNY>
+template <int G, int PF, bool DCNY>
 __device__ __forceinline__ void mac_lds_steps_d2g(v2d (&accr)[8], v2d (&acci)[8], double (&dc)[8], double (&ny)[8],
                                                   v2d (&wr)[8], v2d (&wi)[8], v2d (*s_ring)[2][64], v2d (*s_h)[2][64],
                                                   const v2d *__restrict__ dbase, long duty_slot, bool duty_is_h,
                                                   int nb, int ring, int sl_tb, int lane, int wv, int duty_plane)
 {
-    static_assert(G == 2 || G == 4, "G divides the window period 8; ring entries live 8 steps");
+    static_assert(G == 1 || G == 2 || G == 4, "G divides the window period 8; ring entries live 8 steps");
     constexpr int NH = 2 * G;
     // duty: this wave fetches one plane (re or im; dbase already points at it) of H_s (waves 0, 1) or of
-    // X[tb - s] (waves 2, 3) for every step s, one group of G steps ahead of its use
-    v2d q[G];
+    // X[tb - s] (waves 2, 3) for every step s; the loads run PF groups of G steps ahead of the group being
+    // computed (PF = 2 or 4 measured no faster than 1: global latency is covered; what remains exposed is the LDS
+    // read latency right after each barrier)
+    static_assert((8 / G) % PF == 0, "queue slot of a group is a compile-time constant");
+    v2d q[PF][G];
     int dnext = duty_is_h ? 0 : sl_tb;             // operand index of the step whose load comes next
     auto duty_load = [&]() -> v2d {
         const v2d v = dbase[dnext * duty_slot];
@@ -1124,7 +1127,9 @@ __device__ __forceinline__ void mac_lds_steps_d2g(v2d (&accr)[8], v2d (&acci)[8]
 #pragma unroll
     for (int u = 0; u < G; u++) { const v2d v = duty_load(); duty_store(u, v); }     // steps 0 .. G-1
 #pragma unroll
-    for (int u = 0; u < G; u++) q[u] = duty_load();                                   // steps G .. 2G-1
+    for (int f = 0; f < PF; f++)
+#pragma unroll
+        for (int u = 0; u < G; u++) q[f][u] = duty_load();                            // steps G .. (PF+1) G - 1
     __syncthreads();
     for (int i0 = 0; i0 < nb; i0 += 8) {
 #pragma unroll
@@ -1153,8 +1158,8 @@ __device__ __forceinline__ void mac_lds_steps_d2g(v2d (&accr)[8], v2d (&acci)[8]
                 // publish the operands of the next G steps, refill the queue with those of the G after them
 #pragma unroll
                 for (int u = 0; u < G; u++) {
-                    duty_store(i0 + gi * G + G + u, q[u]);
-                    q[u] = duty_load();
+                    duty_store(i0 + gi * G + G + u, q[gi % PF][u]);
+                    q[gi % PF][u] = duty_load();
                 }
                 __syncthreads();
             }
@@ -1162,7 +1167,7 @@ __device__ __forceinline__ void mac_lds_steps_d2g(v2d (&accr)[8], v2d (&acci)[8]
     }
 }
 
-template <int G>
+template <int G, int PF>
 __global__ __launch_bounds__(256, 2) void k_mac_lds_d2g(MacArgs a, int nbt, int nTQ)
 {
     __shared__ __attribute__((aligned(16))) v2d s_ring[32][2][64];
@@ -1196,9 +1201,9 @@ __global__ __launch_bounds__(256, 2) void k_mac_lds_d2g(MacArgs a, int nbt, int 
     const int plane = wv & 1;
     const v2d *dbase = (duty_is_h ? H : X) + 2 * plane;
     if (bt == 0)   // lane 0 of this tile holds bin 0: DC in the real slot, Nyquist in the imaginary one
-        mac_lds_steps_d2g<G, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+        mac_lds_steps_d2g<G, PF, true>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
     else
-        mac_lds_steps_d2g<G, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
+        mac_lds_steps_d2g<G, PF, false>(accr, acci, dc, ny, wr, wi, s_ring, s_h, dbase, slot, duty_is_h, nb, ring, sl_tb, lane, wv, plane);
     double *__restrict__ Y = (double *)a.y + (long)gc * a.y_ch_stride;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -1218,11 +1223,11 @@ template <int D> static void launch_mac_lds_d2(const MacArgs &a, hipStream_t s)
     hipLaunchKernelGGL((k_mac_lds_d2<D>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
 }
 
-template <int G> static void launch_mac_lds_d2g(const MacArgs &a, hipStream_t s)
+template <int G, int PF> static void launch_mac_lds_d2g(const MacArgs &a, hipStream_t s)
 {
     const int nbt = a.N / 8 / 32;
     const int nTQ = (a.n_t + 31) / 32;
-    hipLaunchKernelGGL((k_mac_lds_d2g<G>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
+    hipLaunchKernelGGL((k_mac_lds_d2g<G, PF>), dim3(nTQ * nbt * a.n_ch), dim3(256), 0, s, a, nbt, nTQ);
 }
 
 template <int D> static void launch_mac_lds_d(const MacArgs &a, hipStream_t s)
@@ -1491,6 +1496,101 @@ static int mac_variant()
 }
 
 // ---------------------------------------------------------------------------
+// k_mac_tstream: partition-streaming MAC out of registers (fp64; grouped layout)
+// ---------------------------------------------------------------------------
+// The transpose of k_mac_stream: a lane owns ONE bin and keeps the sums of TT consecutive output blocks (2 TT
+// values) plus a window of TT delay-line values (2 TT) in registers, and walks the PARTITIONS in order: step p
+// loads h[p] and the one new window value x[t0 - p] (8-byte loads, D steps ahead in a register queue) and feeds
+// all TT outputs, y[t0 + j] += x[t0 + j - p] h[p].  4 TT fused multiply-adds per 32 bytes loaded, no LDS, no
+// barrier -- the LDS-tiled fp64 kernels (k_mac_lds_d2g) spend half their time behind barriers and LDS latency
+// at the two waves per SIMD their 220 registers allow.  Price: the window is re-read by every time tile
+// ((TT + B - 1) / TT spectra per output block instead of (32 + B - 1) / 32) and so is h -- out of L2: the XCD map
+// keeps the time tiles of one (channel, 256-bin column) on one XCD.  Output y[t] receives p = 0 first, B-1
+// last, with the fma chain of every other MAC kernel: bit-identical sums.
+// Measured (profiles/r02_fp64_mac.txt): exactly as fast as the LDS-tiled kernel (0.151 vs 0.158 ms per 4096 blocks at
+// the plug-in's shape, 0.60 vs 0.57 at cfg5's) -- a wave issues DFMAs 31 % of its life and waits for its queue
+// 27 %; two waves per SIMD is all 208 registers allow, and a one-wave-per-SIMD build with 24 outputs and a
+// 12-deep queue in AGPRs is slower (0.68).  Kept as BFIR_MAC64_VARIANT=12, not the default.
+template <typename T, int TT, int D, bool DCNY>
+__device__ __forceinline__ void mac_tstream_body(const MacArgs &a, int gc, int k, int t0)
+{
+    const int N = a.N, ring = a.ring;
+    const T *__restrict__ X = (const T *)a.x + (long)gc * a.x_ch_stride;
+    const T *__restrict__ H = (const T *)a.h + (long)gc * a.h_ch_stride;
+    T *__restrict__ Y = (T *)a.y + (long)gc * a.y_ch_stride;
+    const int nb = a.nblk[gc];
+    const int ore = 8 * (k >> 2) + (k & 3), oim = ore + 4;        // the reference's groups: 4 re then 4 im per 4 bins
+    const int sl0 = (a.base_slot + t0) % ring;                    // delay-line slot of block t0
+    T wr[TT], wi[TT], ar[TT], ai[TT];
+#pragma unroll
+    for (int j = 0; j < TT; j++) {
+        int sj = sl0 + j; if (sj >= ring) sj -= ring;
+        wr[j] = X[(long)sj * N + ore]; wi[j] = X[(long)sj * N + oim];
+        ar[j] = (T)0; ai[j] = (T)0;
+    }
+    // operand queue: step p needs h[p] and x[t0 - p] (p = 0: x[t0], already in the window; loaded anyway)
+    T qhr[D], qhi[D], qxr[D], qxi[D];
+    int ph = 0, sx = sl0;
+    auto fetch = [&](int d) {
+        const int pc = ph < nb ? ph : nb - 1;                     // clamped: in range, never used
+        qhr[d] = H[(long)pc * N + ore]; qhi[d] = H[(long)pc * N + oim];
+        qxr[d] = X[(long)sx * N + ore]; qxi[d] = X[(long)sx * N + oim];
+        ph += 1; sx -= 1; if (sx < 0) sx += ring;
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d);
+    for (int p0 = 0; p0 < nb; p0 += TT) {
+        static_for<0, TT>([&](auto U_) {
+            constexpr int u = decltype(U_)::value;                // = p mod TT
+            if (p0 + u < nb) {                                    // uniform over the grid's channel
+                const T hr = qhr[u % D], hi = qhi[u % D], xr = qxr[u % D], xi = qxi[u % D];
+                fetch(u % D);
+                if (p0 + u > 0) { wr[(TT - u) % TT] = xr; wi[(TT - u) % TT] = xi; }   // block t0 - p takes the slot of t0 + TT - p
+                static_for<0, TT>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value, idx = (j - u + TT) % TT;   // slot holding x[t0 + j - p]
+                    if constexpr (DCNY) {
+                        if (k == 0) {                             // bin 0: DC | Nyquist, two independent real sums
+                            ar[j] = fma(wr[idx], hr, ar[j]); ai[j] = fma(wi[idx], hi, ai[j]);
+                        } else {
+                            ar[j] = fma(wr[idx], hr, ar[j]); ar[j] = fma(-wi[idx], hi, ar[j]);
+                            ai[j] = fma(wr[idx], hi, ai[j]); ai[j] = fma(wi[idx], hr, ai[j]);
+                        }
+                    } else {
+                        ar[j] = fma(wr[idx], hr, ar[j]); ar[j] = fma(-wi[idx], hi, ar[j]);
+                        ai[j] = fma(wr[idx], hi, ai[j]); ai[j] = fma(wi[idx], hr, ai[j]);
+                    }
+                });
+            }
+        });
+    }
+#pragma unroll
+    for (int j = 0; j < TT; j++) {
+        const int t = t0 + j;
+        if (t < a.n_t) { Y[(long)t * N + ore] = ar[j]; Y[(long)t * N + oim] = ai[j]; }
+    }
+}
+
+template <typename T, int TT, int D, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_mac_tstream(MacArgs a, int ncol, int ntile)
+{
+    static_assert(TT % D == 0, "the queue slot of a step is its index mod D in every round");
+    // XCD-aware bijective remap: (channel, bin column) major, time tile minor
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int s = w / ntile, tile = w - s * ntile;
+    const int gc = s / ncol, col = s - gc * ncol;
+    const int k = col * 256 + (int)threadIdx.x;
+    if (col == 0) mac_tstream_body<T, TT, D, true>(a, gc, k, tile * TT);
+    else mac_tstream_body<T, TT, D, false>(a, gc, k, tile * TT);
+}
+
+template <typename T, int TT, int D, int WPS> static void launch_mac_tstream(const MacArgs &a, hipStream_t s)
+{
+    const int ncol = a.N / 2 / 256, ntile = (a.n_t + TT - 1) / TT;     // N >= 512
+    hipLaunchKernelGGL((k_mac_tstream<T, TT, D, WPS>), dim3(ncol * ntile * a.n_ch), dim3(256), 0, s, a, ncol, ntile);
+}
+
+// ---------------------------------------------------------------------------
 // k_mac_small: the sums of a handful of output blocks (the one-block-per-call latency path)
 // ---------------------------------------------------------------------------
 // One lane owns ONE bin of one output block and runs the reference's chain over the partitions in order
@@ -1591,9 +1691,12 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         else launch_mac_t<float, 1, 4, 1>(a, s);
     } else {
         const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid, read per launch
-        if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2g<2>(a, s);     // two bins per lane, 32-block tiles, two partitions per barrier
+        if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2g<2, 1>(a, s);  // two bins per lane, 32-block tiles, two partitions per barrier
+        else if (a.N >= 512 && tt >= 16 && v64 == 12) launch_mac_tstream<double, 16, 4, 2>(a, s);   // partition-streaming, registers only
         else if (a.N >= 512 && tt >= 32 && v64 == 7) launch_mac_lds_d2<2>(a, s);      // ... a barrier per partition
-        else if (a.N >= 512 && tt >= 32 && v64 == 8) launch_mac_lds_d2g<4>(a, s);     // ... four partitions per barrier
+        else if (a.N >= 512 && tt >= 32 && v64 == 8) launch_mac_lds_d2g<4, 1>(a, s);  // ... four partitions per barrier
+        else if (a.N >= 512 && tt >= 32 && v64 == 9) launch_mac_lds_d2g<2, 2>(a, s);  // ... two, loads two groups ahead (no gain:
+                                                                                      // 0.564 vs 0.573 ms; four ahead 0.566; the loads are not what it waits for)
         else if (a.N >= 512 && tt >= 32 && v64 == 4) launch_mac_lds_d2<4>(a, s);
         else if (a.N >= 512 && tt >= 32 && v64 == 5) launch_mac_lds_d2<1>(a, s);
         else if (a.N >= 512 && tt >= 16 && (v64 == 0 || v64 == 6)) launch_mac_lds_d<2>(a, s);

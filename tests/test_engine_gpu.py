@@ -344,3 +344,30 @@ def test_small_launch_mac_kernel_gives_the_bits_of_the_throughput_kernels(orc, b
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     ref = orc.Engine(L, B, s, C); ref.set_coeff(h)
     assert rel_err(outs[0], ref.run(x)[1]) <= TOL[s]
+
+
+@pytest.mark.parametrize("variant", ["7", "8", "9", "12"])
+def test_fp64_mac_variants_give_identical_bits(orc, bfir, variant):
+    """BFIR_MAC64_VARIANT (tuning aid, read per launch) selects other fp64 MAC kernels -- a barrier per partition,
+    four partitions per barrier, deeper prefetch, the register-only partition-streaming kernel: the same chain of
+    fused multiply-adds per bin, so the same bits as the default kernel."""
+    import os
+    L, B, C, nb = 1024, 37, 2, 72          # 72 blocks: two 32-block tiles and a ragged third (16-block tiles: 4 and a half)
+    rng = np.random.default_rng(12)
+    h = orc.synth_ir(rng, C, B * L - 9, np.float64)
+    x = orc.synth_audio(rng, nb * L, C, np.float64)
+    outs = []
+    for v in (None, variant):
+        if v is not None:
+            os.environ["BFIR_MAC64_VARIANT"] = v
+        try:
+            eng = bfir.Brutefir(L, B, 8, C)
+            eng.set_chunk(nb)
+            assert eng.set_coeff(h) == 0
+            outs.append(eng.run(x)[1])
+            eng.close()
+        finally:
+            os.environ.pop("BFIR_MAC64_VARIANT", None)
+    assert np.array_equal(outs[0], outs[1])
+    ref = orc.Engine(L, B, 8, C); ref.set_coeff(h)
+    assert rel_err(outs[0], ref.run(x)[1]) <= TOL[8]

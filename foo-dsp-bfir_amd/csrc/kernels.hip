@@ -1511,21 +1511,27 @@ static int mac_variant()
 // the plug-in's shape, 0.60 vs 0.57 at cfg5's) -- a wave issues DFMAs 31 % of its life and waits for its queue
 // 27 %; two waves per SIMD is all 208 registers allow, and a one-wave-per-SIMD build with 24 outputs and a
 // 12-deep queue in AGPRs is slower (0.68).  Kept as BFIR_MAC64_VARIANT=12, not the default.
-template <typename T, int TT, int D, bool DCNY>
+template <typename T, bool ILV, int TT, int D, bool DCNY>
 __device__ __forceinline__ void mac_tstream_body(const MacArgs &a, int gc, int k, int t0)
 {
+    using V2 = typename Vec2<T>::type;
     const int N = a.N, ring = a.ring;
     const T *__restrict__ X = (const T *)a.x + (long)gc * a.x_ch_stride;
     const T *__restrict__ H = (const T *)a.h + (long)gc * a.h_ch_stride;
     T *__restrict__ Y = (T *)a.y + (long)gc * a.y_ch_stride;
     const int nb = a.nblk[gc];
-    const int ore = 8 * (k >> 2) + (k & 3), oim = ore + 4;        // the reference's groups: 4 re then 4 im per 4 bins
+    // (re, im) pairs (ILV: one load per value) or the reference's groups: 4 re then 4 im per 4 bins (two loads)
+    const int ore = ILV ? 2 * k : 8 * (k >> 2) + (k & 3), oim = ILV ? ore + 1 : ore + 4;
+    auto ld = [&](const T *base, T &re, T &im) {
+        if constexpr (ILV) { const V2 v = *(const V2 *)(base + ore); re = v.x; im = v.y; }
+        else { re = base[ore]; im = base[oim]; }
+    };
     const int sl0 = (a.base_slot + t0) % ring;                    // delay-line slot of block t0
     T wr[TT], wi[TT], ar[TT], ai[TT];
 #pragma unroll
     for (int j = 0; j < TT; j++) {
         int sj = sl0 + j; if (sj >= ring) sj -= ring;
-        wr[j] = X[(long)sj * N + ore]; wi[j] = X[(long)sj * N + oim];
+        ld(X + (long)sj * N, wr[j], wi[j]);
         ar[j] = (T)0; ai[j] = (T)0;
     }
     // operand queue: step p needs h[p] and x[t0 - p] (p = 0: x[t0], already in the window; loaded anyway)
@@ -1533,8 +1539,8 @@ __device__ __forceinline__ void mac_tstream_body(const MacArgs &a, int gc, int k
     int ph = 0, sx = sl0;
     auto fetch = [&](int d) {
         const int pc = ph < nb ? ph : nb - 1;                     // clamped: in range, never used
-        qhr[d] = H[(long)pc * N + ore]; qhi[d] = H[(long)pc * N + oim];
-        qxr[d] = X[(long)sx * N + ore]; qxi[d] = X[(long)sx * N + oim];
+        ld(H + (long)pc * N, qhr[d], qhi[d]);
+        ld(X + (long)sx * N, qxr[d], qxi[d]);
         ph += 1; sx -= 1; if (sx < 0) sx += ring;
     };
 #pragma unroll
@@ -1566,11 +1572,14 @@ __device__ __forceinline__ void mac_tstream_body(const MacArgs &a, int gc, int k
 #pragma unroll
     for (int j = 0; j < TT; j++) {
         const int t = t0 + j;
-        if (t < a.n_t) { Y[(long)t * N + ore] = ar[j]; Y[(long)t * N + oim] = ai[j]; }
+        if (t < a.n_t) {
+            if constexpr (ILV) { V2 v; v.x = ar[j]; v.y = ai[j]; *(V2 *)(Y + (long)t * N + ore) = v; }
+            else { Y[(long)t * N + ore] = ar[j]; Y[(long)t * N + oim] = ai[j]; }
+        }
     }
 }
 
-template <typename T, int TT, int D, int WPS>
+template <typename T, bool ILV, int TT, int D, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_mac_tstream(MacArgs a, int ncol, int ntile)
 {
     static_assert(TT % D == 0, "the queue slot of a step is its index mod D in every round");
@@ -1580,14 +1589,14 @@ __global__ __launch_bounds__(256, WPS) void k_mac_tstream(MacArgs a, int ncol, i
     const int s = w / ntile, tile = w - s * ntile;
     const int gc = s / ncol, col = s - gc * ncol;
     const int k = col * 256 + (int)threadIdx.x;
-    if (col == 0) mac_tstream_body<T, TT, D, true>(a, gc, k, tile * TT);
-    else mac_tstream_body<T, TT, D, false>(a, gc, k, tile * TT);
+    if (col == 0) mac_tstream_body<T, ILV, TT, D, true>(a, gc, k, tile * TT);
+    else mac_tstream_body<T, ILV, TT, D, false>(a, gc, k, tile * TT);
 }
 
-template <typename T, int TT, int D, int WPS> static void launch_mac_tstream(const MacArgs &a, hipStream_t s)
+template <typename T, bool ILV, int TT, int D, int WPS> static void launch_mac_tstream(const MacArgs &a, hipStream_t s)
 {
     const int ncol = a.N / 2 / 256, ntile = (a.n_t + TT - 1) / TT;     // N >= 512
-    hipLaunchKernelGGL((k_mac_tstream<T, TT, D, WPS>), dim3(ncol * ntile * a.n_ch), dim3(256), 0, s, a, ncol, ntile);
+    hipLaunchKernelGGL((k_mac_tstream<T, ILV, TT, D, WPS>), dim3(ncol * ntile * a.n_ch), dim3(256), 0, s, a, ncol, ntile);
 }
 
 // ---------------------------------------------------------------------------
@@ -1666,6 +1675,8 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns
         const int pb = a.B <= 4 ? 4 : a.B <= 8 ? 8 : a.B <= 16 ? 16 : 32;
         const bool batched_only = getenv("BFIR_MAC_BATCHED") != nullptr;   // tuning aid / test hook, read per launch
+        // (k_mac_tstream on the pair layout -- 24 or 32 outputs per lane -- was measured here: +1..5 % over the LDS kernel,
+        // profiles/r02_fp64_mac.txt; not worth a minute of build time per instantiation, so not kept)
         if (a.interleaved && a.B > 32 && tt >= 32 && !batched_only) {
             // more partitions than one register batch: the LDS-shared kernel on the pair layout beats
             // re-reading X and Y once per batch of 32 (profiles/r01_other_configs.txt)
@@ -1692,7 +1703,7 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     } else {
         const int v64 = getenv("BFIR_MAC64_VARIANT") ? atoi(getenv("BFIR_MAC64_VARIANT")) : 0;   // tuning aid, read per launch
         if (a.N >= 512 && tt >= 32 && v64 == 0) launch_mac_lds_d2g<2, 1>(a, s);  // two bins per lane, 32-block tiles, two partitions per barrier
-        else if (a.N >= 512 && tt >= 16 && v64 == 12) launch_mac_tstream<double, 16, 4, 2>(a, s);   // partition-streaming, registers only
+        else if (a.N >= 512 && tt >= 16 && v64 == 12) launch_mac_tstream<double, false, 16, 4, 2>(a, s);   // partition-streaming, registers only
         else if (a.N >= 512 && tt >= 32 && v64 == 7) launch_mac_lds_d2<2>(a, s);      // ... a barrier per partition
         else if (a.N >= 512 && tt >= 32 && v64 == 8) launch_mac_lds_d2g<4, 1>(a, s);  // ... four partitions per barrier
         else if (a.N >= 512 && tt >= 32 && v64 == 9) launch_mac_lds_d2g<2, 2>(a, s);  // ... two, loads two groups ahead (no gain:

@@ -2,7 +2,7 @@
 set -o pipefail
 OUT=gpurun_out/${1:-runs2}
 mkdir -p $OUT
-for combo in "4 2" "4 1" "8 2" "2 2" "4 4" "6 2" "3 2" "4 3"; do
+for combo in "4 4" "2 2" "4 2" "2 4" "8 4" "4 8" "8 8" "1 1" "3 3" "4 4"; do
   set -- $combo
   BFIR_PAIR_RUN_FWD=$1 BFIR_PAIR_RUN_INV=$2 timeout -k 10 300 python bench.py --blocks 32768 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $OUT/r$1_$2.json 2>>$OUT/err.log || { echo "failed"; tail -3 $OUT/err.log; continue; }
   python - <<PY

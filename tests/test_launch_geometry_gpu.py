@@ -54,17 +54,20 @@ def _run_calls(bfir, torch, L, B, s, C, hs, d_in, calls, chunk, env):
     input (the stream of call k+1 continues call k's history).  Returns the outputs as device tensors."""
     n_eng = d_in.shape[0]
     nb_in = d_in.shape[1] // L
+    fb = d_in.element_size()                               # bytes per frame sample: 4 = FLOAT_LE frames, 8 = FLOAT64_LE
+    fmt = 8 if fb == 4 else 10
+    env = {k: v for k, v in env.items() if not k.startswith("_")}
     with _Env(**env):
-        eng = bfir.Brutefir(L, B, s, C, n_engines=n_eng)
+        eng = bfir.Brutefir(L, B, s, C, fmt, fmt, n_engines=n_eng)
         eng.set_chunk(chunk)
         for k in range(n_eng):
             assert eng.set_coeff(hs[k], engine_index=k) == 0
-        stride = nb_in * L * C * s
+        stride = nb_in * L * C * fb
         outs = []
         for n in calls:
             d_out = torch.empty((n_eng, n * L, C), dtype=d_in.dtype, device=d_in.device)
             eng.run_device(d_in.data_ptr(), d_out.data_ptr(), n, in_stride_bytes=stride,
-                           out_stride_bytes=n * L * C * s, stream=torch.cuda.current_stream().cuda_stream)
+                           out_stride_bytes=n * L * C * fb, stream=torch.cuda.current_stream().cuda_stream)
             assert eng.sync() == 0
             outs.append(d_out)
         for c in range(n_eng * C):
@@ -107,7 +110,7 @@ def _sample_points(calls, chunk, ring, rng_of):
     return sorted(pts)
 
 
-def _check(orc, torch, L, B, s, C, hs, x_host, calls, outs, chunk, rng_of, max_points=28):
+def _check(orc, torch, L, B, s, C, hs, x_host, calls, outs, chunk, rng_of, max_points=28, fmt=None):
     """Sampled oracle parity.  x_host: [n_eng, nb_in*L, C]; call k reads blocks 0 .. calls[k]-1 of it."""
     ring = 2 * chunk + B
     pts = _sample_points(calls, chunk, ring, rng_of)
@@ -126,12 +129,12 @@ def _check(orc, torch, L, B, s, C, hs, x_host, calls, outs, chunk, rng_of, max_p
     worst = 0.0
     for e in range(x_host.shape[0]):
         glob = [int(starts[ci] + t) for ci, t in pts]
-        ref = orc.sampled_reference(hs[e], lambda g: block_of(e, g), glob, L, B, s, C)
+        ref = orc.sampled_reference(hs[e], lambda g: block_of(e, g), glob, L, B, s, C, fmt, fmt)
         for (ci, t), g in zip(pts, glob):
             y = outs[ci][e, t * L:(t + 1) * L].cpu().numpy().astype(np.float64)
             r = ref[g].astype(np.float64)
             err = float(np.abs(y - r).max() / np.abs(r).max())
-            assert err <= TOL[s], (e, ci, t, err)
+            assert err <= (TOL[4] if fmt == 8 else TOL[s]), (e, ci, t, err)     # float32 output frames round to 6e-8
             worst = max(worst, err)
     return worst, len(pts)
 
@@ -158,6 +161,10 @@ GEOMETRIES = [
     ("plugin_stereo_8_launches", 4, 1024, 64, 2, 1, 4096, [4096, 100], 512, {}),
     # configs[1]: largest pair-path partition
     ("cfg2_L8192", 4, 8192, 8, 2, 1, 1024, [1024, 1024, 3], 1024, {}),
+    # the plug-in as shipped: REALSIZE 8 arithmetic, FILTER_LEN 1024, float32 stereo frames, 64 partitions -- both
+    # channels of a block in one workgroup (direct mode), fp64 LDS MAC with two partitions per barrier, 4096-block
+    # launches, three engines sharing them, then a one-block call (k_mac_small)
+    ("plugin_fp64_f32frames_4096", 8, 1024, 64, 2, 3, 4096, [4096, 1000, 1], 4096, {"_FRAMES": "f32"}),
 ]
 
 
@@ -168,7 +175,8 @@ def test_large_launches_match_oracle_and_small_launches(orc, bfir, name, s, L, B
     hs = _synth(orc, s, C, taps, n_eng, seed=len(name) + L)
     rng = np.random.default_rng(B + C)
     rdt = orc.real_dtype(s)
-    if s == 4:
+    f32 = s == 4 or env.get("_FRAMES") == "f32"
+    if f32:
         x_host = rng.random((n_eng, nb * L, C), dtype=np.float32)
         x_host *= 2.0; x_host -= 1.0
     else:
@@ -178,7 +186,8 @@ def test_large_launches_match_oracle_and_small_launches(orc, bfir, name, s, L, B
     big = _run_calls(bfir, torch, L, B, s, C, hs, d_in, calls, chunk, env)
     ilv = s == 4                                           # fp32 engines with N >= 512 use the streaming MAC family
     rng_of = (lambda tc: _mac_range(tc, 2 * L, n_eng * C, B, env)) if ilv else (lambda tc: 0)
-    worst, n_pts = _check(orc, torch, L, B, s, C, hs, x_host, calls, big, chunk, rng_of)
+    worst, n_pts = _check(orc, torch, L, B, s, C, hs, x_host, calls, big, chunk, rng_of,
+                          fmt=8 if (s == 8 and f32) else None)
 
     # every block, bit for bit, against 64-block launches (ngrp = 1: the geometry checked in full elsewhere)
     env_small = {k: v for k, v in env.items() if k != "BFIR_MAC_RANGE"}

@@ -1510,7 +1510,8 @@ static int mac_variant()
 // Measured (profiles/r02_fp64_mac.txt): exactly as fast as the LDS-tiled kernel (0.151 vs 0.158 ms per 4096 blocks at
 // the plug-in's shape, 0.60 vs 0.57 at cfg5's) -- a wave issues DFMAs 31 % of its life and waits for its queue
 // 27 %; two waves per SIMD is all 208 registers allow, and a one-wave-per-SIMD build with 24 outputs and a
-// 12-deep queue in AGPRs is slower (0.68).  Kept as BFIR_MAC64_VARIANT=12, not the default.
+// 12-deep queue in AGPRs is slower (0.68), 12 outputs per lane at three waves per SIMD the same (0.154-0.163 / 0.63).
+// Kept as BFIR_MAC64_VARIANT=12, not the default.
 template <typename T, bool ILV, int TT, int D, bool DCNY>
 __device__ __forceinline__ void mac_tstream_body(const MacArgs &a, int gc, int k, int t0)
 {

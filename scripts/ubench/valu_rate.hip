@@ -9,7 +9,7 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// MODE 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_add_f32, 3 v_pk_mul_f32, 4 v_add_f32, 5 v_fma_f64
+// MODE 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_add_f32, 3 v_pk_mul_f32, 4 v_add_f32, 5 v_fma_f64, 6 / 7 the MAC's operand pattern (f64 / f32)
 template <int MODE> __global__ void k(float *out, int iters, float a0, float b0)
 {
     float acc[32];
@@ -17,7 +17,34 @@ template <int MODE> __global__ void k(float *out, int iters, float a0, float b0)
     const v2f a2 = {a, a + 1e-9f}, b2 = {b, b - 1e-9f};
 #pragma unroll
     for (int j = 0; j < 32; j++) acc[j] = threadIdx.x * 0.001f + j;
-    if (MODE == 5) {
+    if (MODE == 6 || MODE == 7) {
+        // the MAC's operand pattern: acc[j] = fma(x[j], h, acc[j]) -- one operand repeated, two fresh register pairs
+        // per instruction (MODE 6: f64, MODE 7: f32 with 32 chains)
+        if (MODE == 6) {
+            double d[16], e[16];
+            const double da = a;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { d[j] = acc[j]; e[j] = acc[j + 16] * 1e-3; }
+            for (int it = 0; it < iters; it++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) d[j] = __builtin_fma(e[j], da, d[j]);
+#pragma unroll
+                for (int j = 0; j < 16; j++) asm volatile("" : "+v"(e[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] = (float)d[j];
+        } else {
+            float e[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) e[j] = acc[j] * 1e-3f;
+            for (int it = 0; it < iters; it++) {
+#pragma unroll
+                for (int j = 0; j < 32; j++) acc[j] = __builtin_fmaf(e[j], a, acc[j]);
+#pragma unroll
+                for (int j = 0; j < 32; j++) asm volatile("" : "+v"(e[j]));
+            }
+        }
+    } else if (MODE == 5) {
         double d[16];
         const double da = a, db = b;
 #pragma unroll
@@ -64,8 +91,8 @@ template <int MODE> void run(const char *name, int wpe)
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int instr = (MODE == 0 || MODE == 4) ? 32 : 16;
-    const double lane_ops = (double)blocks * 256 * iters * (MODE == 5 ? 16 : 32);
+    const int instr = (MODE == 0 || MODE == 4 || MODE == 7) ? 32 : 16;
+    const double lane_ops = (double)blocks * 256 * iters * ((MODE == 5 || MODE == 6) ? 16 : 32);
     const double wave_instr_per_simd = (double)wpe * iters * instr;   // 1 wave per SIMD per block
     printf("%-12s waves/SIMD %d: %.3f ms  %.1f Tops/s (x2 = FLOP/s for fma)  %.2f ns per wave-instr per SIMD\n",
            name, wpe, ms, lane_ops / ms / 1e9, ms * 1e6 / wave_instr_per_simd);
@@ -80,5 +107,7 @@ int main()
     for (int w : {1, 2, 4}) run<2>("v_pk_add_f32", w);
     for (int w : {1, 2, 4}) run<3>("v_pk_mul_f32", w);
     for (int w : {1, 2, 4}) run<5>("v_fma_f64", w);
+    for (int w : {1, 2, 3, 4}) run<6>("v_fma_f64 acc+=x*h", w);
+    for (int w : {1, 2, 3, 4}) run<7>("v_fma_f32 acc+=x*h", w);
     return 0;
 }

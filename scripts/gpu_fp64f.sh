@@ -1,11 +1,12 @@
 #!/bin/bash
-# fp64 MAC: partitions per barrier x prefetch distance (BFIR_MAC64_VARIANT 0 = 2 per barrier / 1 group ahead, 9 = 2 / 2, 10 = 2 / 4, 11 = 1 / 4, 7 = round-2a kernel)
+# fp64 MAC: partitions per barrier x prefetch distance (BFIR_MAC64_VARIANT 0 = 2 per barrier / 1 group ahead, 9 = 2 / 2, 8 = 4 per barrier, 7 = round-2a kernel;
+# the 2 / 4 and 1 / 4 builds of profiles/r02_fp64_mac.txt were removed again)
 set -o pipefail
 OUT=gpurun_out/${1:-fp64f}; mkdir -p $OUT
-for v in 9 10 11; do
+for v in 9; do
   BFIR_MAC64_VARIANT=$v timeout -k 10 600 python -m pytest tests/test_launch_geometry_gpu.py tests/test_engine_gpu.py -m gpu -x -q -k "fp64 or 8-" > $OUT/pytest_v$v.log 2>&1; echo "variant $v pytest rc=$?"; tail -1 $OUT/pytest_v$v.log
 done
-for v in 0 9 10 11 7 0; do
+for v in 0 9 7 8 0; do
   for wl in cfg5_2ch_262144tap_L4096_fp64 plugin_2ch_65536tap_L1024_fp64_f32frames; do
     BFIR_MAC64_VARIANT=$v timeout -k 10 300 python bench.py --workload $wl --blocks 16384 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $OUT/${wl}_$v.json 2>>$OUT/err.log || { echo "$wl v$v failed"; tail -3 $OUT/err.log; continue; }
     python - <<PY

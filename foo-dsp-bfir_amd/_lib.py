@@ -42,7 +42,7 @@ class DitherState(C.Structure):
 
 LOG_FN = C.CFUNCTYPE(None, C.c_char_p)
 
-_vp, _ci, _cd, _cl = C.c_void_p, C.c_int, C.c_double, C.c_long
+_vp, _ci, _cd, _cl = C.c_void_p, C.c_int, C.c_double, C.c_int64   # 64-bit fields are int64_t in the header, never `long`
 _pi = C.POINTER(C.c_int)
 
 # every symbol include/bfir_hip.h declares: name -> (restype, argtypes)

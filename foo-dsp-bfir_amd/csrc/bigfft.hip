@@ -251,7 +251,7 @@ extern "C" int bfir_fft_plan_execute(bfir_fft_plan *p, const void *in, void *out
     return p->realsize == 4 ? execute_t<float>(p, in, out) : execute_t<double>(p, in, out);
 }
 
-extern "C" long bfir_fft_plan_length(const bfir_fft_plan *p) { return p ? p->n : 0; }
+extern "C" int64_t bfir_fft_plan_length(const bfir_fft_plan *p) { return p ? p->n : 0; }
 
 // ---------------------------------------------------------------------------
 // equalizer::render_f / render_d (brutefir/equalizer.cpp:211-299, 301-394)

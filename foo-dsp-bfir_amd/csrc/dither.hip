@@ -68,10 +68,16 @@ void dither_fill_table(std::vector<int8_t> &tab, int n_channels, int spacing)
 
 // ---- device ------------------------------------------------------------------------------------
 // dither_randmap[d] (dither.cpp:73-104), evaluated in double as there and narrowed to T
+// The table entry is a rounded product added to a rounded sum: no fused multiply-add (the library is built with
+// -ffp-contract=on, which would otherwise fuse this one expression; the reference is an SSE2 build, the CPU checker
+// a gcc build without FMA).  Entry -256 is the table's exact -0.5 (unreachable from two int8 bytes, kept for the mirror).
 template <typename T> __device__ __forceinline__ T dither_map(int d)
 {
+#pragma clang fp contract(off)
     if (d == 254) return (T)1.5;
-    return (T)(0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (double)d);
+    if (d <= -256) return (T)-0.5;
+    const double prod = 1.0 / 255.0 * (double)d;
+    return (T)((0.5 + 1.0 / 255.0) + prod);
 }
 
 template <typename T> struct DitherRun {
@@ -258,11 +264,13 @@ extern "C" void bfir_dither_preloop_real2int_hp_tpdf(bfir_dither *d, bfir_dither
 // real2raw{f,d}_hp_tpdf of one block (n samples of `d_src` on the device, working precision) into the
 // strided device buffer d_raw; `state` and `overflow` are the caller's (host) structs.  The preloop
 // must have been called for this block.  Used by bfir_convolver_cbuf2raw_dither (stage.hip).
-int bfir_dither_run_block(bfir_dither *d, const void *d_src, void *d_raw, int fmt, int spacing, int n,
+int bfir_dither_realsize(const bfir_dither *d) { return d ? d->realsize : 0; }
+
+int bfir_dither_run_block(bfir_dither *d, int realsize, const void *d_src, void *d_raw, int fmt, int spacing, int n,
                           bfir_dither_state *state, bfir_overflow *overflow, hipStream_t s)
 {
     const FmtInfo fi = fmt_info(fmt);
-    if (!fi.bytes || fi.isfloat) return BFIR_ERR_ARG;
+    if (!fi.bytes || fi.isfloat || realsize != d->realsize) return BFIR_ERR_ARG;   // d_src holds `realsize`-byte reals
     const long off = state->randtab - d->tab.data();       // where the preloop put this block
     if (off < 1 || off + n > (long)d->tab.size()) return BFIR_ERR_ARG;
     const int prev = (int)d->tab[off - 1];                 // honours the host-side rewrite of slot 0

@@ -536,7 +536,7 @@ extern "C" int bfir_engine_set_profiling(bfir_engine *e, int enable)
     return BFIR_OK;
 }
 
-extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total_ms, long *launches)
+extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total_ms, int64_t *launches)
 {
     if (!e || kernel < 0 || kernel >= BFIR_K_COUNT) return BFIR_ERR_ARG;
     drain_spans(e);
@@ -818,8 +818,8 @@ static int ensure_chunk(bfir_engine *e, int n_blocks)
     return BFIR_OK;
 }
 
-extern "C" int bfir_engine_run_device(bfir_engine *e, const void *d_in, long in_stride_bytes,
-                                      void *d_out, long out_stride_bytes, int n_blocks, void *hip_stream)
+extern "C" int bfir_engine_run_device(bfir_engine *e, const void *d_in, int64_t in_stride_bytes,
+                                      void *d_out, int64_t out_stride_bytes, int n_blocks, void *hip_stream)
 {
     if (!e || !d_in || !d_out || n_blocks < 0) return BFIR_ERR_ARG;
     if (!bfir_engine_is_initialized(e)) return BFIR_ERR_STATE;

@@ -493,8 +493,14 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned v
     return f;
 }
 
+// Minimum waves per SIMD the inverse kernel is compiled for.  Four (128 registers) everywhere but N = 4096, whose
+// last pass is a radix-16 one with six base twiddles in registers: at 128 it spills ONE register, and a spill is a
+// scratch (vector-memory) operation inside the window the hand-counted vmcnt spans -- the wait would then cover
+// one operation too few.  scripts/audit_ps_isa.py (tests/test_isa_audit.py) found it and checks every build.
+template <int LOG2N> constexpr int inv_ps_min_waves() { return LOG2N == 12 ? 3 : 4; }
+
 template <int LOG2N>
-__global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_inv_pair_ps(InvPairArgs a, const float2 *__restrict__ twb, int run_len)
+__global__ __launch_bounds__(FftCfg<LOG2N>::NT, inv_ps_min_waves<LOG2N>()) void k_inv_pair_ps(InvPairArgs a, const float2 *__restrict__ twb, int run_len)
 {
     using F = LdsFft<float, LOG2N, +1>;
     constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, Q = P / 4;   // Q 16-byte pieces per thread and spectrum

@@ -275,8 +275,9 @@ extern "C" int bfir_convolver_cbuf2raw(bfir_convolver *c, const void *cbuf, void
     return BFIR_OK;
 }
 
-int bfir_dither_run_block(bfir_dither *d, const void *d_src, void *d_raw, int fmt, int spacing, int n,
+int bfir_dither_run_block(bfir_dither *d, int realsize, const void *d_src, void *d_raw, int fmt, int spacing, int n,
                           bfir_dither_state *state, bfir_overflow *overflow, hipStream_t s);   // dither.hip
+int bfir_dither_realsize(const bfir_dither *d);                                                   // dither.hip
 
 extern "C" int bfir_convolver_cbuf2raw_dither(bfir_convolver *c, bfir_dither *d, const void *cbuf, void *outbuf,
                                               const bfir_buffer_format *bf, bfir_dither_state *dither_state,
@@ -287,6 +288,9 @@ extern "C" int bfir_convolver_cbuf2raw_dither(bfir_convolver *c, bfir_dither *d,
     if (rc != BFIR_OK) return rc;
     if (bf->sf.isfloat) return bfir_convolver_cbuf2raw(c, cbuf, outbuf, bf, overflow);   // fftw_convolver.cpp:421
     if (!d || !dither_state) { bfir_logf("Dither instance not set."); return BFIR_ERR_ARG; }   // :412-416
+    // the reference builds both with one realsize (brutefir.cpp:709-719); a dither of the other precision would
+    // read this convolver's samples as the wrong type
+    if (bfir_dither_realsize(d) != c->s) { bfir_logf("Dither instance and convolver differ in realsize."); return BFIR_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     const size_t span = ((size_t)(c->L - 1) * bf->sample_spacing + 1) * bf->sf.bytes;
     rc = need_raw(c, span);
@@ -295,7 +299,7 @@ extern "C" int bfir_convolver_cbuf2raw_dither(bfir_convolver *c, bfir_dither *d,
     HIP_TRY(hipMemcpyAsync(c->d_raw, dst, span, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d[0], cbuf, (size_t)c->L * c->s, hipMemcpyHostToDevice, c->stream));
     bfir_dither_preloop_real2int_hp_tpdf(d, dither_state, c->L);
-    rc = bfir_dither_run_block(d, c->d[0], c->d_raw, bf->sf.format, bf->sample_spacing, c->L, dither_state, overflow,
+    rc = bfir_dither_run_block(d, c->s, c->d[0], c->d_raw, bf->sf.format, bf->sample_spacing, c->L, dither_state, overflow,
                                c->stream);
     if (rc != BFIR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(dst, c->d_raw, span, hipMemcpyDeviceToHost, c->stream));

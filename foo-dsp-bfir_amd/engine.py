@@ -147,7 +147,7 @@ class Brutefir:
         """{kernel name: (total_ms, launches)} measured with HIP events."""
         out = {}
         for k, name in enumerate(_lib.KERNEL_NAMES):
-            ms, n = C.c_double(0), C.c_long(0)
+            ms, n = C.c_double(0), C.c_int64(0)
             self._lib.bfir_engine_get_profile(self._h, k, C.byref(ms), C.byref(n))
             out[name] = (ms.value, n.value)
         return out

@@ -44,6 +44,11 @@ static_assert(sizeof(dither_state_t) == sizeof(bfir_dither_state), "dither_state
 static_assert(offsetof(dither_state_t, sd) == offsetof(bfir_dither_state, sd), "dither_state_t layout");
 static_assert(sizeof(bfoverflow_t) == sizeof(bfir_overflow), "bfoverflow_t layout");
 static_assert(offsetof(bfoverflow_t, max) == offsetof(bfir_overflow, max), "bfoverflow_t layout");
+// 64-bit quantities of the C ABI are int64_t whatever the platform's `long` is (MSVC: 32 bits)
+static_assert(sizeof(int64_t) == 8, "int64_t");
+static_assert(__is_same(decltype(&bfir_engine_run_device),
+                        int (*)(bfir_engine *, const void *, int64_t, void *, int64_t, int, void *)), "engine strides are int64_t");
+static_assert(__is_same(decltype(&bfir_fft_plan_length), int64_t (*)(const bfir_fft_plan *)), "plan lengths are int64_t");
 
 #ifndef CONVOLVER_MIXMODE_INPUT
 #define CONVOLVER_MIXMODE_INPUT BFIR_MIXMODE_INPUT

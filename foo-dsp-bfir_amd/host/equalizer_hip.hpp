@@ -73,18 +73,31 @@ public:
         return path;
     }
 
-    // equalizer::make_filename (:152-180): DJB hash over the raw band doubles, signed chars
-    std::string make_filename(int n_bands, const double *freq, const double *mag, const double *phase) const
+    // DJBHash (brutefir/hash.c:113-124) over plain chars, which are signed on the reference's compiler and here;
+    // pinned against the reference's own function by tests/golden/djb_hash_ref.json
+    static unsigned int djb_hash(const char *str, size_t len)
+    {
+        unsigned int hash = 5381;
+        for (size_t i = 0; i < len; i++) hash = ((hash << 5) + hash) + (unsigned int)(int)(signed char)str[i];
+        return hash;
+    }
+    // equalizer::make_filename (:152-180): the hash of the raw freq | mag | phase doubles, in hex, then
+    // taps/2, realsize, channels, sampling rate
+    static std::string make_filename_for(int taps, int realsize, int n_channels, int sampling_rate, int n_bands,
+                                         const double *freq, const double *mag, const double *phase)
     {
         std::vector<char> blob(3 * (size_t)n_bands * sizeof(double));
         memcpy(blob.data(), freq, n_bands * sizeof(double));
         memcpy(blob.data() + n_bands * sizeof(double), mag, n_bands * sizeof(double));
         memcpy(blob.data() + 2 * n_bands * sizeof(double), phase, n_bands * sizeof(double));
-        unsigned int hash = 5381;
-        for (char ch : blob) hash = ((hash << 5) + hash) + (unsigned int)(int)(signed char)ch;   // hash.c:113-124
         char name[128];
-        snprintf(name, sizeof(name), "eq-%x-%d-%d-%d-%d.wav", hash, m_taps >> 1, m_realsize, m_channels, m_rate);
+        snprintf(name, sizeof(name), "eq-%x-%d-%d-%d-%d.wav", djb_hash(blob.data(), blob.size()), taps >> 1, realsize,
+                 n_channels, sampling_rate);
         return name;
+    }
+    std::string make_filename(int n_bands, const double *freq, const double *mag, const double *phase) const
+    {
+        return make_filename_for(m_taps, m_realsize, m_channels, m_rate, n_bands, freq, mag, phase);
     }
 
 private:

@@ -101,13 +101,48 @@ inline bool calculate_attenuation(const void *coeffs, int n_channels, int n_fram
     for (int c = 0; c < n_channels; c++) ptrs[c] = taps[c].data();
     if (filter.set_coeff(ptrs.data(), n_channels, filter_length, filter_blocks, 1.0) != 0) return false;   // :313
     std::vector<uint8_t> outbuf((size_t)length * n_channels * realsize, 0);
-    if (filter.run_blocks(const_cast<void *>(noise), outbuf.data(), filter_blocks) != 0) return true;   // no block counted
-    // the largest |y| over all channels is what the engine's overflow bookkeeping tracks
     double max_value = 0;
-    for (int c = 0; c < n_channels; c++) {
-        bfir_overflow of;
-        bfir_engine_get_overflow(filter.handle(), c, &of);
-        if (of.largest > max_value) max_value = of.largest;
+    if (filter.run_blocks(const_cast<void *>(noise), outbuf.data(), filter_blocks) == 0) {
+        // every run() succeeded: the largest |y| over all channels is what the engine's overflow bookkeeping tracks
+        for (int c = 0; c < n_channels; c++) {
+            bfir_overflow of;
+            bfir_engine_get_overflow(filter.handle(), c, &of);
+            if (of.largest > max_value) max_value = of.largest;
+        }
+    } else {
+        // Some run() failed.  The reference's loop (preprocessor.cpp:329-356) skips the scan of THAT block and goes
+        // on; and because brutefir::run returns before it flips curbuf and advances blockcounter (brutefir.cpp:316-321,
+        // 337-340), the failed block never enters the history: the next call overwrites its delay-line slot and its
+        // half of the time buffer.  Replayed block by block; after a failure the engine is rebuilt from the blocks
+        // that were kept so far (an error path: no need to be fast).
+        const size_t blk = (size_t)filter_length * n_channels * realsize;
+        std::vector<int> kept;
+        std::vector<uint8_t> hist, scratch;
+        brutefir *f = nullptr;
+        auto rebuild = [&]() -> bool {
+            delete f;
+            f = new brutefir(filter_length, filter_blocks, realsize, n_channels, detail::fmt_for(realsize),
+                             detail::fmt_for(realsize), 44100, false, device);
+            if (f->set_coeff(ptrs.data(), n_channels, filter_length, filter_blocks, 1.0) != 0) return false;
+            if (kept.empty()) return true;
+            hist.resize(kept.size() * blk); scratch.resize(hist.size());
+            for (size_t i = 0; i < kept.size(); i++) memcpy(&hist[i * blk], (const uint8_t *)noise + (size_t)kept[i] * blk, blk);
+            return f->run_blocks(hist.data(), scratch.data(), (int)kept.size()) == 0;
+        };
+        bool ok = rebuild();
+        for (int n = 0; ok && n < filter_blocks; n++) {
+            if (f->run((uint8_t *)const_cast<void *>(noise) + (size_t)n * blk, outbuf.data()) == 0) {
+                kept.push_back(n);
+                for (size_t i = 0; i < (size_t)filter_length * n_channels; i++) {   // :336-354, NaN never compares greater
+                    const double v = realsize == 4 ? (double)fabsf(((const float *)outbuf.data())[i]) : fabs(((const double *)outbuf.data())[i]);
+                    if (v > max_value) max_value = v;
+                }
+            } else {
+                ok = rebuild();
+            }
+        }
+        delete f;
+        if (!ok) return false;
     }
     if (max_value > 1) *attenuation = -20.0 * log10(max_value);              // -TO_DB, util.hpp:15
     return true;

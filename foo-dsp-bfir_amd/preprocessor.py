@@ -77,18 +77,49 @@ def calculate_attenuation(coeffs, filter_length, realsize, noise, device=0, make
     n_frames, n_channels = coeffs.shape
     length = get_next_multiple(n_frames, filter_length)
     filter_blocks = length // filter_length
-    flt = make_engine(filter_length, filter_blocks, realsize, n_channels, _fmt(realsize), _fmt(realsize),
-                      device=device) if make_engine is Brutefir else make_engine(
-                          filter_length, filter_blocks, realsize, n_channels)
     taps = [np.ascontiguousarray(_pad_frames(coeffs, filter_length * filter_blocks, dt)[:, c])
             for c in range(n_channels)]
-    flt.set_coeff(taps, n_channels, filter_length, filter_blocks, 1.0)     # :313 (length = filter_length)
+
+    def new_filter():
+        f = make_engine(filter_length, filter_blocks, realsize, n_channels, _fmt(realsize), _fmt(realsize),
+                        device=device) if make_engine is Brutefir else make_engine(
+                            filter_length, filter_blocks, realsize, n_channels)
+        f.set_coeff(taps, n_channels, filter_length, filter_blocks, 1.0)   # :313 (length = filter_length)
+        return f
+
+    flt = new_filter()
     noise = np.ascontiguousarray(noise, dtype=dt)
     assert noise.shape == (filter_length * filter_blocks, n_channels)
     rc, out = flt.run(noise)
-    max_value = float(np.abs(out).max()) if rc == 0 else 0.0               # :336-354
-    # the engine's overflow peak is the same number without reading the output back
-    if rc == 0 and hasattr(flt, "overflow"):
-        peak = max(flt.overflow(c).largest for c in range(n_channels))
-        assert peak == max_value
+    if rc == 0:
+        max_value = float(np.abs(out).max())                               # :336-354
+        # the engine's overflow peak is the same number without reading the output back
+        if hasattr(flt, "overflow"):
+            peak = max(flt.overflow(c).largest for c in range(n_channels))
+            assert peak == max_value
+    else:
+        max_value = _scan_block_by_block(new_filter, noise, filter_length, filter_blocks)
     return -20.0 * math.log10(max_value) if max_value > 1.0 else 0.0
+
+
+def _scan_block_by_block(new_filter, noise, L, n_blocks):
+    """The reference's loop when some run() fails (preprocessor.cpp:329-356): the failed block's output is not
+    scanned and the loop goes on.  brutefir::run returns before it flips curbuf and advances blockcounter
+    (brutefir.cpp:316-321, 337-340), so the failed block never enters the history -- the next call overwrites its
+    delay-line slot and its half of the time buffer.  After a failure the filter is rebuilt from the blocks kept
+    so far (an error path)."""
+    kept, max_value = [], 0.0
+    flt = new_filter()
+    for n in range(n_blocks):
+        rc, out = flt.run(noise[n * L:(n + 1) * L])
+        if rc == 0:
+            kept.append(n)
+            a = np.abs(out)
+            a = a[a == a]                                                  # a NaN never compares greater (:340-352)
+            if a.size:
+                max_value = max(max_value, float(a.max()))
+        else:
+            flt = new_filter()
+            if kept and flt.run(np.concatenate([noise[k * L:(k + 1) * L] for k in kept]))[0] != 0:
+                raise RuntimeError("blocks that passed before fail on replay")
+    return max_value

@@ -144,9 +144,11 @@ int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, int n_block
 /* The same on DEVICE memory, asynchronous on `hip_stream` (a hipStream_t;
  * NULL = the engine's own stream).  Engine k reads d_in + k*in_stride_bytes
  * and writes d_out + k*out_stride_bytes.  The NaN verdict is delivered by
- * bfir_engine_sync. */
-int bfir_engine_run_device(bfir_engine *e, const void *d_in, long in_stride_bytes, void *d_out,
-                           long out_stride_bytes, int n_blocks, void *hip_stream);
+ * bfir_engine_sync.  Strides, counts and lengths that can pass 2^31 are int64_t,
+ * never `long`: the reference's platform is MSVC (brutefir/brutefir.vcxproj:66-70),
+ * where `long` has 32 bits, and one 8-channel stream of a day's audio is a 32 GiB stride. */
+int bfir_engine_run_device(bfir_engine *e, const void *d_in, int64_t in_stride_bytes, void *d_out,
+                           int64_t out_stride_bytes, int n_blocks, void *hip_stream);
 /* Wait for all queued work; 0, or BFIR_ERR_NONFINITE if any block since the
  * last sync produced a non-finite first sample. */
 int bfir_engine_sync(bfir_engine *e);
@@ -165,7 +167,7 @@ int bfir_engine_set_chunk(bfir_engine *e, int blocks_per_launch);
 enum { BFIR_K_STAGE_IN = 0, BFIR_K_FWD = 1, BFIR_K_MAC = 2, BFIR_K_INV = 3, BFIR_K_STAGE_OUT = 4,
        BFIR_K_COUNT = 5 };
 int bfir_engine_set_profiling(bfir_engine *e, int enable);
-int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total_ms, long *launches);
+int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total_ms, int64_t *launches);
 
 /* copy partition spectrum `block` of global channel `channel` to host (n_fft reals) */
 int bfir_engine_read_coeff(bfir_engine *e, int channel, int block, void *dst);
@@ -257,7 +259,7 @@ void bfir_fft_plan_destroy(bfir_fft_plan *p);
 /* fftw[f]_execute_r2r(plan, in, out) on host buffers of 2^order reals; in == out allowed
  * (replaces the direct FFTW calls at equalizer.cpp:262, 357). */
 int bfir_fft_plan_execute(bfir_fft_plan *p, const void *in, void *out);
-long bfir_fft_plan_length(const bfir_fft_plan *p);
+int64_t bfir_fft_plan_length(const bfir_fft_plan *p);
 /* equalizer::render_f / render_d (equalizer.cpp:211-299, 301-394): band tables as
  * equalizer::generate leaves them (:113-118) -> taps/2-sample impulse response in ir_out.
  * ifftplan: an HC2R plan of `taps` reals. */

@@ -23,6 +23,18 @@ def test_header_is_plain_c():
     subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", HEADER], check=True)
 
 
+def test_no_long_in_the_abi():
+    """The reference's platform is MSVC (brutefir/brutefir.vcxproj:66-70), where `long` has 32 bits: every
+    stride, count and length that can pass 2^31 is int64_t / size_t."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    assert not re.search(r"\blong\b", src), [l for l in src.splitlines() if re.search(r"\blong\b", l)]
+    assert re.search(r"bfir_engine_run_device\([^)]*int64_t in_stride_bytes[^)]*int64_t out_stride_bytes", src)
+    from importlib import import_module
+    sigs = import_module("foo_dsp_bfir_amd._lib").SIGNATURES
+    assert sigs["bfir_engine_run_device"][1][2] is C.c_int64 and sigs["bfir_engine_run_device"][1][4] is C.c_int64
+    assert sigs["bfir_fft_plan_length"][0] is C.c_int64
+
+
 def test_library_exports_every_declared_symbol(bfir):
     lib = bfir.load()
     names = _declared_functions()

@@ -66,6 +66,13 @@ def test_cbuf2raw_dither_needs_the_instance(bfir):
     st = bfir.Dither(1, 100, 4, 0, 64).states[0]
     with pytest.raises(bfir.BfirError):                      # "Dither instance not set." (fftw_convolver.cpp:412-416)
         cv.convolver_cbuf2raw(np.zeros(128, np.float32), np.zeros((64, 1), "<i2"), make_buffer_format(2, 0, 1), of, True, st)
+    # a dither built for the other precision would read the convolver's samples as the wrong type: refused
+    # (the reference builds both with one realsize, brutefir.cpp:709-719)
+    d8 = bfir.Dither(1, 100, 8, 0, 64)
+    cv._dither = d8
+    with pytest.raises(bfir.BfirError):
+        cv.convolver_cbuf2raw(np.zeros(128, np.float32), np.zeros((64, 1), "<i2"), make_buffer_format(2, 0, 1), of, True,
+                              d8.states[0])
 
 
 def _planar(bfir, *a, **kw):

@@ -228,6 +228,31 @@ def test_run_device_on_torch_stream(orc, bfir):
     assert eng.sync() == 0
 
 
+def test_engine_strides_beyond_4_gib(orc, bfir):
+    """The engines of a batch may lie more than 2^32 bytes apart (the bench's own 8-channel stream is a 32 GiB
+    stride): the C ABI carries the strides as int64_t (include/bfir_hip.h), the kernels as 64-bit offsets."""
+    import torch
+    s, L, B, C, nb, E = 4, 1024, 3, 2, 6, 2
+    stride = (4 << 30) + 65536                                   # bytes between engine 0 and engine 1
+    hs = [_make(orc, s, C, B * L, nb * L, seed=70 + e)[0] for e in range(E)]
+    xs = [_make(orc, s, C, B * L, nb * L, seed=80 + e)[1] for e in range(E)]
+    d_in = torch.zeros(stride + nb * L * C * 4, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros_like(d_in)
+    for e in range(E):
+        raw = torch.from_numpy(xs[e].view(np.uint8).reshape(-1)).cuda()
+        d_in[e * stride:e * stride + raw.numel()] = raw
+    eng = bfir.Brutefir(L, B, s, C, n_engines=E)
+    for e in range(E):
+        assert eng.set_coeff(hs[e], engine_index=e) == 0
+    eng.run_device(d_in.data_ptr(), d_out.data_ptr(), nb, in_stride_bytes=stride, out_stride_bytes=stride)
+    assert eng.sync() == 0
+    for e in range(E):
+        y = d_out[e * stride:e * stride + nb * L * C * 4].cpu().numpy().view(np.float32).reshape(nb * L, C)
+        ref = orc.Engine(L, B, s, C); ref.set_coeff(hs[e])
+        assert rel_err(y, ref.run(xs[e])[1]) <= TOL[s]
+    eng.close()
+
+
 def test_create_rejects_bad_arguments(bfir):
     for args in [(1000, 2, 4, 2), (1024, 2, 6, 2), (1024, 2, 4, 9), (1024, 0, 4, 2), (8, 2, 4, 2),
                  (16384, 2, 8, 1)]:

@@ -108,20 +108,36 @@ def measured_traffic_table(workload, chunk):
 
 
 def measured_stream_peaks():
-    """Best read / write / copy GB/s of scripts/ubench/hbm_stream.hip on this GPU model
-    (profiles/r01_hbm_stream.txt; SURVEY 8(d) asks for the measured stream peak next to the 8 TB/s spec)."""
+    """Best read / write / copy GB/s of scripts/ubench/hbm_stream2.hip on this GPU model
+    (profiles/r03_hbm_stream.txt; SURVEY 8(d) asks for the measured stream peak next to the 8 TB/s spec).
+    copy_GBs counts read + written bytes of a 1 : 1 mix -- the mix the convolution pipeline moves."""
     import re
-    path = os.path.join(ROOT, "profiles", "r01_hbm_stream.txt")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_stream.txt")
     best = {}
     try:
         for line in open(path):
-            for key in ("read", "write", "copy"):
-                m = re.search(key + r" (\d+) GB/s", line)
-                if m:
-                    best[key + "_GBs"] = max(best.get(key + "_GBs", 0), int(m.group(1)))
+            m = re.match(r"^(read|write|copy)[, ].*?(\d+) GB/s\s*$", line)
+            if m:
+                key = m.group(1) + "_GBs"
+                best[key] = max(best.get(key, 0), int(m.group(2)))
     except OSError:
         return None
+    if best:
+        best["source"] = "profiles/r03_hbm_stream.txt (contiguous slab per workgroup; grid-stride loops reach 4.6-4.8 copy)"
     return best or None
+
+
+def flops_per_block(C, B, N):
+    """Arithmetic of one run() block: 8 flops per complex multiply-add over C * B * N/2 bins, and a forward and an
+    inverse real transform per channel at 2.5 N log2 N (two channels share one N-point complex transform on the
+    pair path: 5 N log2 N per pair and direction -- the same count)."""
+    import math
+    return {"mac": 8.0 * C * B * (N // 2), "fft": 2 * C * 2.5 * N * math.log2(N)}
+
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md; fp64 vector: half of it
+# bytes a three-kernel pipeline (fwd | mac | inv, spectra handed over through memory) cannot avoid, per block:
+# input in, delay-line spectrum out + in, product spectrum out + in, output out
 
 
 def cpu_model():
@@ -220,9 +236,15 @@ def spawn_check(args):
     total = sharding.sum_over_ranks(10.0)
     lo, hi = sharding.shard_range(8, rank, world)
     chans = sharding.sum_over_ranks(hi - lo)
+    # configs[3]: 256 stereo streams dealt out to the ranks; the widest share bounds a rank's memory
+    slo, shi = sharding.shard_range(256, rank, world)
+    streams = sharding.sum_over_ranks(shi - slo)
+    widest = sharding.max_over_ranks(shi - slo)
+    most_ch = sharding.max_over_ranks(hi - lo)
     if rank == 0:
         print(json.dumps({"spawn_check": True, "n_gpus": world, "max_elapsed": worst, "sum_units": total,
-                          "channels_covered": chans}), flush=True)
+                          "channels_covered": chans, "channels_rank0": hi - lo, "channels_max": most_ch,
+                          "streams_covered": streams, "streams_rank0": shi - slo, "streams_max": widest}), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
@@ -465,18 +487,15 @@ def main():
             dom = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[dom]
             blocks_per_launch = n_eng * args.steps * nb / launches   # engine-blocks in one launch
-            achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic.get(dom) if traffic else None,
-                        "frac_is": "this kernel's share of SURVEY 8(d)'s algorithmic bytes (see DESIGN 6) over its own "
-                                   "mean launch time while sharing the GPU with the other two kernels; "
-                                   "pipeline.* is the whole path",
-                        "traffic_source": traffic_file or "none matching this csrc/ (stale files are refused)",
+            roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            dom_achieved = alg[dom] * blocks_per_launch / (ms / launches * 1e-3) / 1e9
+            dominant = {"kernel": dom, "avg_launch_ms": round(ms / launches, 5),
                         "algorithmic_bytes_per_launch": int(alg[dom] * blocks_per_launch),
-                        "avg_launch_ms": round(ms / launches, 5),
-                        "kernel_ms_share": {k: round(v[0] / max(sum(p[0] for p in prof.values()), 1e-12), 4)
-                                            for k, v in prof.items()}}
+                        "achieved": round(dom_achieved, 1), "frac": round(dom_achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic.get(dom) if traffic else None,
+                        "what": "the kernel with the most launch time: ITS share of SURVEY 8(d)'s algorithmic bytes over "
+                                "ITS mean launch duration (HIP events on its stream, inside the timed region, while it "
+                                "shares the GPU with the other two kernels)"}
             per = {}
             for kname, (kms, kl) in prof.items():
                 if not kl:
@@ -486,22 +505,52 @@ def main():
                 per[kname] = {"avg_launch_ms": round(kms / kl, 5), "algorithmic_bytes_per_launch": int(alg[kname] * bpl),
                               "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic.get(kname) if traffic else None}
-            roofline["kernels"] = per
-            roofline["peak_measured"] = measured_stream_peaks()
             # whole path: one launch set (fwd + mac + inv of one chunk) per elapsed/launches of wall time
             ms_set = elapsed * 1e3 / max(launches, 1)
             alg_set = sum(alg.values()) * blocks_per_launch
             compulsory = (2 * C * s * L) * blocks_per_launch          # input once in, output once out
+            three_kernel_floor = (2 * C * s * L + 4 * C * s * N) * blocks_per_launch   # + X and Y each written and read once
+            tset = sum(traffic.get(k, 0) for k in per) if traffic else None
+            fl = flops_per_block(C, B, N)
+            flops_set = (fl["mac"] + fl["fft"]) * blocks_per_launch
+            valu_peak = FP32_VECTOR_PEAK_TFLOPS * (1.0 if s == 4 else 0.5)
+            moved = tset if tset else three_kernel_floor
+            rate = moved / (ms_set * 1e-3) / 1e9
+            peaks = measured_stream_peaks()
+            roofline.update({
+                "kernel": "fwd | mac | inv pipeline of one launch set (three kernels sharing the GPU; most launch time: %s)" % dom,
+                "achieved": round(rate, 1),
+                "frac": round(rate / HBM_PEAK_GBS, 4),
+                "traffic": int(tset) if tset else None,
+                "frac_is": ("bytes at the L2's memory side per launch set (rocprofv3 PMC, %s) / wall time per launch set / 8 TB/s"
+                            % traffic_file) if tset else
+                           ("NO counter file matches this csrc/: bytes a three-kernel pipeline cannot avoid (input, output, "
+                            "X and Y spectra each written and read once) / wall time per launch set / 8 TB/s -- a lower "
+                            "bound on the traffic, see traffic_source"),
+                "traffic_source": traffic_file or "none matching this csrc/ (stale files are refused)",
+                "useful_frac": round(compulsory / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "useful_frac_is": "compulsory bytes (input once in, output once out) / wall / 8 TB/s",
+                "literal_8d_x_peak": round(alg_set / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "literal_8d_is": "SURVEY 8(d)'s streaming bytes (every block re-reads all partition and delay-line spectra) "
+                                 "/ wall / 8 TB/s: above 1 because those bytes are not moved -- the MAC keeps a bin's "
+                                 "partitions in registers across the blocks in flight (8(d) caveat 2)",
+                "valu_frac": round(flops_set / (ms_set * 1e-3) / 1e12 / valu_peak, 4),
+                "valu_frac_is": "(MAC + FFT flops per launch set) / wall / %.1f TFLOP/s vector peak" % valu_peak,
+                "frac_of_measured_mixed_stream": round(rate / peaks["copy_GBs"], 4) if peaks and peaks.get("copy_GBs") else None,
+                "ms_per_launch_set": round(ms_set, 5),
+                "dominant_kernel": dominant,
+                "kernels": per,
+                "peak_measured": peaks,
+            })
             pipe = {"ms_per_launch_set": round(ms_set, 5),
-                    "algorithmic_GBs": round(alg_set / (ms_set * 1e-3) / 1e9, 1),
-                    "algorithmic_frac_of_peak": round(alg_set / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_launch_set": int(alg_set),
                     "compulsory_bytes_per_launch_set": int(compulsory),
-                    "compulsory_GBs": round(compulsory / (ms_set * 1e-3) / 1e9, 1)}
-            if traffic:
-                tset = sum(traffic.get(k, 0) for k in per)
+                    "three_kernel_floor_bytes_per_launch_set": int(three_kernel_floor),
+                    "flops_per_launch_set": int(flops_set),
+                    "TFLOPs": round(flops_set / (ms_set * 1e-3) / 1e12, 2)}
+            if tset:
                 pipe.update({"traffic_bytes_per_launch_set": int(tset),
                              "traffic_GBs": round(tset / (ms_set * 1e-3) / 1e9, 1),
-                             "traffic_frac_of_peak": round(tset / (ms_set * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic_over_compulsory": round(tset / compulsory, 3)})
             roofline["pipeline"] = pipe
             # The timed region runs fwd(k+1), mac(k) and inv(k-1) concurrently on three streams, so
@@ -510,12 +559,6 @@ def main():
             if exclusive is not None:
                 ex = {k: v[0] / max(v[1], 1) for k, v in exclusive.items() if v[1]}
                 roofline["exclusive_launch_ms"] = {k: round(v, 5) for k, v in ex.items()}
-                if dom in ex:
-                    a_ex = alg[dom] * blocks_per_launch / (ex[dom] * 1e-3) / 1e9
-                    roofline["achieved_exclusive"] = round(a_ex, 1)
-                    roofline["frac_exclusive"] = round(a_ex / HBM_PEAK_GBS, 4)
-                    if roofline["traffic"]:
-                        roofline["traffic_rate_exclusive_GBs"] = round(roofline["traffic"] / (ex[dom] * 1e-3) / 1e9, 1)
                 for kname, v in per.items():
                     if kname in ex:
                         v["exclusive_launch_ms"] = round(ex[kname], 5)

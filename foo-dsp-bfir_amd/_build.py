@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbfir_hip.so")
-SOURCES = ["kernels.hip", "engine.hip", "stage.hip", "bigfft.hip", "pair.hip", "dither.hip"]
+SOURCES = ["kernels.hip", "engine.hip", "stage.hip", "bigfft.hip", "pair.hip", "dither.hip", "mac_sys.hip"]
 HEADERS = ["kernels.h", "fft_lds.h", os.path.join("..", "..", "include", "bfir_hip.h")]
 # -ffp-contract=on: fuse only inside one source expression (the stage kernels rely on it);
 # -fno-slp-vectorize: packing the FFT butterflies into v_pk_* costs more moves than it saves
@@ -68,16 +68,20 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, extra_flags, verbose=False):
+def build_variant(name, extra_flags, verbose=False, only=None):
     """Tuning aid: a second build of the library with extra hipcc flags (-D experiment switches) into
     lib/variant_<name>/ -> lib/libbfir_hip_<name>.so, leaving the product library alone.  Select it for
-    one process with BFIR_LIB_OVERRIDE (A/B timing of two builds inside one gpurun call)."""
+    one process with BFIR_LIB_OVERRIDE (A/B timing of two builds inside one gpurun call).
+    only: recompile just these sources with the extra flags and link the product build's objects for the rest."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     vdir = os.path.join(LIBDIR, "variant_" + name)
     os.makedirs(vdir, exist_ok=True)
     flags = [f for f in FLAGS] + list(extra_flags)
     objs, jobs = [], []
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(LIBDIR, src.replace(".hip", ".o")))
+            continue
         o = os.path.join(vdir, src.replace(".hip", ".o"))
         jobs.append([hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)

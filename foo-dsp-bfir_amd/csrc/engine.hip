@@ -813,6 +813,10 @@ static int ensure_chunk(bfir_engine *e, int n_blocks)
         const long slots = (long)((4ull << 30) / ((size_t)e->GC * cbuf_bytes(e)));
         limit = (int)std::max(16L, std::min(4096L, (slots - e->B) / 2));
     }
+    // HP-TPDF dither is a recursion over a channel's samples (dither.hip: one lane walks them in order), so a
+    // launch's length is its run time: bound it (64 blocks: the serial walk stays in the milliseconds and the
+    // other kernels of the pipeline get the GPU in between; integer outputs are off the measured path)
+    if (e->d_dither_tab) limit = std::min(limit, 64);
     const int want = std::max(1, std::min(limit, n_blocks));
     if (want > e->chunk) return alloc_work(e, want);
     return BFIR_OK;

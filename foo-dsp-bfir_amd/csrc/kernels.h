@@ -156,6 +156,9 @@ inline int bfir_alias_env(const char *name) { const char *e = getenv(name); retu
 #define BFIR_YSLOT(a, t) (t)
 #endif
 void launch_mac(const MacArgs &a, hipStream_t s);
+// mac_sys.hip: the forward-walking two-lanes-per-bin form of the fp32 pair-layout MAC (B <= 32)
+bool mac_sys_supported(const MacArgs &a);
+void launch_mac_sys(const MacArgs &a, hipStream_t s);
 
 // a11 + a12: inverse real FFT of Y[gc][t] (grouped layout, times in_scale),
 // first L samples to dst + gc*dst_ch_stride + t*L.

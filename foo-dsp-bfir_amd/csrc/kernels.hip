@@ -1685,6 +1685,9 @@ void launch_mac(const MacArgs &a, hipStream_t s)
             return;
         }
         if (a.interleaved) {                          // the engine picked the pair layout (fp32, N >= 512)
+            // BFIR_MAC_SYS=1: the forward-walking systolic kernel (mac_sys.hip); read per launch (tests switch it in-process)
+            const char *ms = getenv("BFIR_MAC_SYS");
+            if (ms && atoi(ms) != 0 && mac_sys_supported(a) && !batched_only) { launch_mac_sys(a, s); return; }
             if (pb == 4) launch_mac_stream<4, 4>(a, s);
             else if (pb == 8) launch_mac_stream<8, 8>(a, s);
             else if (pb == 16) launch_mac_stream<16, 8>(a, s);

@@ -282,10 +282,11 @@ def parse_args(argv=None):
 
 
 def auto_chunk(n_ch, N, B, s):
-    """The engine's automatic blocks-per-launch (csrc/engine.hip ensure_chunk): 4096, fewer when the
-    delay line of that many blocks would pass 4 GiB."""
+    """The engine's automatic blocks-per-launch (csrc/engine.hip ensure_chunk): the work of 4096 headline-shaped
+    blocks (4096 ... 32768 blocks), fewer when the delay line of that many blocks would pass 4 GiB."""
     slots = (4 << 30) // (n_ch * N * s)
-    return int(max(16, min(4096, (slots - B) // 2)))
+    want = max(4096, min(32768, (8 * 4096 * 4096) // (n_ch * (N // 2))))
+    return int(max(16, min(want, (slots - B) // 2)))
 
 
 def default_blocks(n_eng, C, L, B, s, chunk):

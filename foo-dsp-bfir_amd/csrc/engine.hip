@@ -806,12 +806,17 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
 
 static int ensure_chunk(bfir_engine *e, int n_blocks)
 {
-    // automatic: 4096 blocks per launch (measured best for long jobs, profiles/r01_bench_chunk_sweep.jsonl),
-    // less when the delay line of that many blocks would pass 4 GiB (many channels or engines)
+    // automatic: as many blocks per launch as give a launch the work of 4096 blocks of the 8-channel, 4096-sample
+    // headline shape (measured best for long jobs, profiles/r01_bench_chunk_sweep.jsonl) -- small engines need longer
+    // launches to keep the three kernels of the pipeline overlapped (the stereo plug-in shape: +12 % fp64 / +19 % fp32
+    // at 32768 blocks per launch against 4096, profiles/r03_chunk.txt) -- between 4096 and 32768, less when the
+    // delay line of that many blocks would pass 4 GiB (many channels or engines)
     int limit = e->want_chunk;
     if (limit <= 0) {
         const long slots = (long)((4ull << 30) / ((size_t)e->GC * cbuf_bytes(e)));
-        limit = (int)std::max(16L, std::min(4096L, (slots - e->B) / 2));
+        long want = (8L * 4096 * 4096) / ((long)e->GC * e->L);
+        want = std::max(4096L, std::min(32768L, want));
+        limit = (int)std::max(16L, std::min(want, (slots - e->B) / 2));
     }
     // HP-TPDF dither is a recursion over a channel's samples (dither.hip: one lane walks them in order), so a
     // launch's length is its run time: bound it (64 blocks: the serial walk stays in the milliseconds and the

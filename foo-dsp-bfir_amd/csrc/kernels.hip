@@ -1671,6 +1671,15 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     if (a.n_t <= 0 || a.n_ch <= 0) return;
     const int tt = a.n_t;
     if (tt <= BFIR_MAC_SMALL_MAX && !getenv("BFIR_NO_MAC_SMALL")) { launch_mac_small(a, s); return; }   // env: A/B and tests
+    {   // The forward-walking systolic kernel (mac_sys.hip: fp32 pairs layout up to 128 partitions, fp64 grouped layout
+        // up to 64): the default for fp64 (cfg5 +12 %, its MAC -20 % against the LDS-tiled kernel) and for fp32 with more
+        // than 32 partitions (+1..5 % against k_mac_lds); with up to 32 partitions k_mac_stream stays ahead (0.49 against
+        // 0.59 ms per 4096 headline blocks: two lanes per bin double the vector-memory instructions per FMA,
+        // profiles/r03_mac_sys.txt).  BFIR_MAC_SYS=1 / 0 forces / forbids it; read per launch (tests switch it in-process).
+        const char *ms = getenv("BFIR_MAC_SYS");
+        const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || a.B > 32) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
+        if (want && mac_sys_supported(a) && !getenv("BFIR_MAC_BATCHED")) { launch_mac_sys(a, s); return; }
+    }
     if (a.realsize == 4) {
         const int v = mac_variant();
         // time-streaming kernel: PB partitions of a bin in registers per batch, whole 256-bin columns
@@ -1685,9 +1694,6 @@ void launch_mac(const MacArgs &a, hipStream_t s)
             return;
         }
         if (a.interleaved) {                          // the engine picked the pair layout (fp32, N >= 512)
-            // BFIR_MAC_SYS=1: the forward-walking systolic kernel (mac_sys.hip); read per launch (tests switch it in-process)
-            const char *ms = getenv("BFIR_MAC_SYS");
-            if (ms && atoi(ms) != 0 && mac_sys_supported(a) && !batched_only) { launch_mac_sys(a, s); return; }
             if (pb == 4) launch_mac_stream<4, 4>(a, s);
             else if (pb == 8) launch_mac_stream<8, 8>(a, s);
             else if (pb == 16) launch_mac_stream<16, 8>(a, s);

@@ -159,8 +159,9 @@ void bfir_engine_reset(bfir_engine *e);
 /* copy of brutefir's overflow[channel] (brutefir.cpp:326-334) */
 int bfir_engine_get_overflow(bfir_engine *e, int channel, bfir_overflow *of);
 
-/* tuning: blocks per launch; 0 (the default) = automatic: 4096, less when the delay line of that many
- * blocks would pass 4 GiB, at most 512 on the host-pointer path; takes effect on the next run */
+/* tuning: blocks per launch; 0 (the default) = automatic: the work of 4096 blocks of the 8-channel, 4096-sample
+ * headline shape (4096 ... 32768 blocks), less when the delay line of that many blocks would pass 4 GiB, at most 512
+ * on the host-pointer path; takes effect on the next run */
 int bfir_engine_set_chunk(bfir_engine *e, int blocks_per_launch);
 
 /* per-kernel timing with HIP events on the stream the kernels run on */

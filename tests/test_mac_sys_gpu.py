@@ -1,11 +1,13 @@
-"""k_mac_sys (csrc/mac_sys.hip): the forward-walking, two-lanes-per-bin form of the partition sums.
+"""k_mac_sys (csrc/mac_sys.hip): the forward-walking form of the partition sums, S adjacent lanes per bin.
 
 Every output is ONE fused multiply-add chain over the partitions in the reference's order (brutefir/brutefir.cpp:
-288-299, fftw_convolver.cpp:1464-1525), exactly the chain of k_mac_stream -- so the two kernels must agree BIT FOR
-BIT on every block, whatever the launch geometry: run lengths that are no multiple of the slot group, runs shorter
-than the filter, the ring wrap inside a run (the two lane halves pass it 2 PL / 2 + 1 slots apart), partition counts
-below 2 PL (zero partitions), ragged last partitions, several engines, call-to-call continuation.  The streaming
-kernel itself is checked against the oracle throughout the suite; one shape here goes to the oracle directly."""
+288-299, fftw_convolver.cpp:1464-1525 / 2160-2220), exactly the chain of the default MAC kernels (k_mac_stream,
+k_mac_lds on the pair layout, the fp64 LDS kernel) -- so it must agree with them BIT FOR BIT on every block, whatever
+the launch geometry: run lengths that are no multiple of the slot group, runs shorter than the filter, the ring wrap
+inside a run (the stages pass it PL + 1 slots apart), partition counts below S PL (zero partitions), ragged last
+partitions, several engines, call-to-call continuation, two / four / eight lanes per bin, fp32 (pairs layout) and fp64
+(the reference's grouped layout).  The default kernels are checked against the oracle throughout the suite; two shapes
+here go to the oracle directly."""
 import numpy as np
 import pytest
 
@@ -13,7 +15,7 @@ from test_launch_geometry_gpu import _check, _run_calls, _synth
 
 pytestmark = pytest.mark.gpu
 
-# name, L, B, C, n_eng, blocks resident, calls, chunk, extra env
+# name, L, B, C, n_eng, blocks resident, calls, chunk, extra env  (a leading "d_" = realsize 8)
 SHAPES = [
     ("headline_wrap", 4096, 32, 8, 1, 700, [700, 37, 700, 1, 5], 700, {}),          # ring 1432 wraps in the third call
     ("headline_short_runs", 4096, 32, 8, 1, 300, [300, 300], 300, {"BFIR_MAC_RANGE": "33"}),
@@ -25,16 +27,26 @@ SHAPES = [
     ("B16_PL8", 512, 16, 6, 1, 300, [300, 300], 300, {"BFIR_MAC_RANGE": "50"}),
     ("B3_PL4", 1024, 3, 2, 2, 200, [200, 200, 6], 100, {}),
     ("B8_PL4_L256", 256, 8, 2, 1, 500, [500, 500], 500, {"BFIR_MAC_RANGE": "21"}),
+    # four and eight lanes per bin (fp32, more than 32 partitions: the default there is the LDS-shared kernel)
+    ("B64_S4", 1024, 64, 2, 1, 400, [400, 77, 400], 400, {}),
+    ("B40_S4_short_runs", 512, 40, 4, 1, 300, [300, 300], 150, {"BFIR_MAC_RANGE": "25"}),
+    ("B100_S8", 1024, 100, 2, 1, 300, [300, 300, 5], 300, {}),
+    # fp64, grouped layout: the plug-in's shipped precision (REALSIZE 8, common.h:17), cfg5's partition count
+    ("d_B64_S4_plugin", 1024, 64, 2, 1, 300, [300, 40, 300], 300, {}),
+    ("d_B64_S4_L4096_wrap", 4096, 64, 2, 1, 200, [200, 200, 200], 100, {"BFIR_MAC_RANGE": "37"}),
+    ("d_B20_S2", 512, 20, 3, 2, 200, [200, 200], 200, {}),
+    ("d_B9_S2_PL8", 256, 9, 2, 1, 300, [300, 300], 300, {"BFIR_MAC_RANGE": "11"}),
 ]
 
 
 @pytest.mark.parametrize("name,L,B,C,n_eng,nb,calls,chunk,env", SHAPES, ids=[g[0] for g in SHAPES])
 def test_systolic_mac_is_bit_identical_to_the_streaming_mac(orc, bfir, name, L, B, C, n_eng, nb, calls, chunk, env):
     import torch
-    s = 4
+    s = 8 if name.startswith("d_") else 4
+    dt = np.float32 if s == 4 else np.float64
     hs = _synth(orc, s, C, B * L - 37, n_eng, seed=len(name) + L)
     rng = np.random.default_rng(B + C)
-    x_host = rng.random((n_eng, nb * L, C), dtype=np.float32)
+    x_host = rng.random((n_eng, nb * L, C), dtype=dt)
     x_host *= 2.0; x_host -= 1.0
     d_in = torch.from_numpy(x_host).cuda()
     stream_env = {k: v for k, v in env.items() if k != "BFIR_MAC_RANGE"}
@@ -45,6 +57,6 @@ def test_systolic_mac_is_bit_identical_to_the_streaming_mac(orc, bfir, name, L, 
             diff = (a != b).any(dim=2).view(n_eng, -1, L).any(dim=2)           # [engine, block]
             bad = diff.nonzero()[:8].tolist()
             raise AssertionError("call %d: %d blocks differ, first (engine, block): %s" % (ci, int(diff.sum()), bad))
-    if name == "headline_wrap":
+    if name in ("headline_wrap", "d_B64_S4_plugin"):
         worst, n_pts = _check(orc, torch, L, B, s, C, hs, x_host, calls, got, chunk, lambda tc: 0)
         print("oracle: %d sampled blocks, worst rel err %.3g" % (n_pts, worst))

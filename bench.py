@@ -277,6 +277,7 @@ def parse_args(argv=None):
                     help="process-group backend for the timing reduction (nccl = RCCL; gloo lets several "
                          "ranks rehearse the N > 1 path on one GPU together with --device)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
+    ap.add_argument("--channels", type=int, default=0, help="override the workload's channel count (1..8); the line's config says so")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -338,6 +339,8 @@ def main():
     from foo_dsp_bfir_amd import sharding
 
     C_all, taps, L, s = WORKLOADS[args.workload][:4]
+    if args.channels > 0:
+        C_all = args.channels          # the workload's shape with another channel count (tuning aid / odd-channel-count runs)
     fb = WORKLOADS[args.workload][4] if len(WORKLOADS[args.workload]) > 4 else s     # bytes per frame sample
     fmt = 8 if fb == 4 else 10                                                          # BF_SAMPLE_FORMAT_FLOAT_LE / FLOAT64_LE
     N, B = 2 * L, (taps + L - 1) // L

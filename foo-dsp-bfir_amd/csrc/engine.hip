@@ -127,6 +127,8 @@ struct bfir_engine {
     // tails[set][i] = [n_eng][L][C] floats, set alternating per chunk so a launch never reads and
     // writes the same copy; hist_raw[i] is where input_timecbuf[n][i]'s first half currently lives.
     bool pair = false;
+    // ... with an odd channel count (or one channel) the pairs are blocks t, t + 1 of ONE channel (k_fwd_tp_ps / k_inv_tp_ps)
+    bool pair_tp = false;
     // direct path: any other engine whose frames are FLOAT_LE / FLOAT64_LE in and out (fp64 arithmetic, odd
     // channel counts, partitions outside the pair kernels' range): k_fwd reads the raw frames itself and
     // k_inv writes them, one channel per transform; same history bookkeeping as the pair path (tails of raw
@@ -273,8 +275,13 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
     }
     {   // BFIR_PAIR=0 (tuning aid) keeps the planar staging kernels
         const char *pv = getenv("BFIR_PAIR");
-        e->pair = e->ilv && in_format == 8 && out_format == 8 && (channels % 2) == 0 &&
+        // the persistent kernels only (BFIR_PAIR_PERSIST=0 keeps odd channel counts on the general path)
+        const char *pp = getenv("BFIR_PAIR_PERSIST"), *tv = getenv("BFIR_PAIR_TIME");
+        const bool tp_ok = !(pp && atoi(pp) != 1) && !(tv && atoi(tv) == 0);
+        e->pair_tp = (channels % 2) == 1 && tp_ok;
+        e->pair = e->ilv && in_format == 8 && out_format == 8 && ((channels % 2) == 0 || e->pair_tp) &&
                   pair_supported(filter_length) && !(pv && atoi(pv) == 0);
+        e->pair_tp = e->pair_tp && e->pair;
         const char *dv = getenv("BFIR_DIRECT");
         // worth it where a channel's samples are 8 bytes apart or wider units: FLOAT64 frames (any C), or one
         // channel (contiguous samples), or stereo float frames (the reference plug-in's own shape), which k_fwd /
@@ -566,8 +573,8 @@ extern "C" int bfir_engine_get_profile(bfir_engine *e, int kernel, double *total
 static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void *d_out, long out_stride,
                           long frame_off, int tc, int block_base, hipStream_t st, hipEvent_t input_ready)
 {
-    if (((uintptr_t)d_in | (uintptr_t)d_out | (uintptr_t)in_stride | (uintptr_t)out_stride) & 7) {
-        bfir_logf("bfir engine: frame buffers of the float fast path must be 8-byte aligned.");
+    if (((uintptr_t)d_in | (uintptr_t)d_out | (uintptr_t)in_stride | (uintptr_t)out_stride) & (e->pair_tp ? 3 : 7)) {
+        bfir_logf("bfir engine: frame buffers of the float fast path must be 8-byte aligned (4 with an odd channel count).");
         return BFIR_ERR_ARG;
     }
     const int par = (int)(e->chunk_seq & 1);
@@ -590,6 +597,7 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.hist_eng_stride = (long)e->L * e->C;
         a.dst = (float *)e->X; a.dst_ch_stride = (long)e->ring * e->N; a.ring = e->ring; a.base_slot = base_slot;
         a.scale = (float)e->in_scale;
+        a.tp = e->pair_tp;
         launch_fwd_pair(e->plan2, a, sf);
     }
     e->hist_raw[0] = e->tails[par][0]; e->hist_raw[1] = e->tails[par][1];
@@ -622,6 +630,7 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.C = e->C; a.n_eng = e->n_eng; a.n_t = tc;
         a.scale = (float)e->out_scale; a.max = (float)e->of_max;
         a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.tp = e->pair_tp;
         launch_inv_pair(e->plan2, a, st);
     }
     if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));

@@ -193,6 +193,7 @@ struct FwdPairArgs {
     long hist_eng_stride;                                // floats between engines in prev / save_* / carry
     float *dst; long dst_ch_stride; int ring, base_slot; // delay line, (re, im) pairs
     float scale;
+    int tp = 0;                                          // pairs in TIME: blocks t, t+1 of one channel per transform (any C)
 };
 void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a, hipStream_t s);
 struct InvPairArgs {
@@ -202,6 +203,7 @@ struct InvPairArgs {
     float scale, max;
     DevOverflow *overflow; int *bad_block; int block_base;
     long of_shard_stride = 0;
+    int tp = 0;                                          // pairs in time, as in FwdPairArgs
 #ifdef BFIR_EXPERIMENT_ALIAS
     int y_alias = 1 << 30;
 #endif

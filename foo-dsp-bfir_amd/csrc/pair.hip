@@ -305,6 +305,39 @@ __device__ __forceinline__ void asm_prefetch2x4x4(u32x4 (&a)[4], u32x4 (&b)[4], 
                  : "v"(voff), "s"(ra), "s"(rb), "s"(s1), "s"(s2), "s"(s3)
                  : "memory");
 }
+// 2 x 8 x 4 bytes per lane (time pairs: one channel's samples of two blocks): b[e] <- buffer B[voff + e * step], c[e] <- buffer C[...]
+__device__ __forceinline__ void asm_prefetch2x8x1(unsigned (&b)[8], unsigned (&c)[8], unsigned voff, i32x4 rb, i32x4 rc, unsigned step)
+{
+    const unsigned s1 = __builtin_amdgcn_readfirstlane(step), s2 = 2 * s1, s3 = 3 * s1, s4 = 4 * s1, s5 = 5 * s1, s6 = 6 * s1, s7 = 7 * s1;
+    asm volatile("s_nop 4\n\t"
+                 "buffer_load_dword %0, %16, %17, 0 offen\n\t"
+                 "buffer_load_dword %8, %16, %18, 0 offen\n\t"
+                 "buffer_load_dword %1, %16, %17, %19 offen\n\t"
+                 "buffer_load_dword %9, %16, %18, %19 offen\n\t"
+                 "buffer_load_dword %2, %16, %17, %20 offen\n\t"
+                 "buffer_load_dword %10, %16, %18, %20 offen\n\t"
+                 "buffer_load_dword %3, %16, %17, %21 offen\n\t"
+                 "buffer_load_dword %11, %16, %18, %21 offen\n\t"
+                 "buffer_load_dword %4, %16, %17, %22 offen\n\t"
+                 "buffer_load_dword %12, %16, %18, %22 offen\n\t"
+                 "buffer_load_dword %5, %16, %17, %23 offen\n\t"
+                 "buffer_load_dword %13, %16, %18, %23 offen\n\t"
+                 "buffer_load_dword %6, %16, %17, %24 offen\n\t"
+                 "buffer_load_dword %14, %16, %18, %24 offen\n\t"
+                 "buffer_load_dword %7, %16, %17, %25 offen\n\t"
+                 "buffer_load_dword %15, %16, %18, %25 offen"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+                 : "v"(voff), "s"(rb), "s"(rc), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void asm_wait_vmcnt(unsigned (&b)[8], unsigned (&c)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+                 : "n"(N) : "memory");
+}
 // wait until all but the N youngest vector-memory operations of this wave are done; names the prefetch
 // destinations so that no use of them is scheduled above it
 template <int N, typename V, int K> __device__ __forceinline__ void asm_wait_vmcnt(V (&d)[K])
@@ -480,6 +513,157 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_pair_ps(FwdPairArg
     asm_wait_vmcnt<0>(nxt);
 }
 
+// ---- persistent forward kernel, pairs in TIME ------------------------------------------------------------
+// The same two-for-one transform for engines whose channels cannot be paired (an odd channel count, one channel --
+// the 8-GPU point of a channel-sharded stream): blocks t and t + 1 of ONE channel are the real and the imaginary part,
+//
+//     z[n] = w_t[n] + i w_{t+1}[n],     w_t = [block t-1 | block t]   (the window brutefir.cpp:255-263 transforms),
+//
+// so that X_a is block t's delay-line spectrum and X_b block t + 1's -- channels never mix (brutefir.cpp:252-334), and
+// the split, the scaling and every rounding are those of the channel-pair kernel: the spectra are the SAME numbers
+// whichever way the blocks are paired up.  One workgroup walks a run of an even number of blocks of one channel; a
+// thread keeps its 8 samples of block t + 1 (the next window's "previous block") in registers, fetches blocks
+// t + 2 and t + 3 (4-byte samples at the frame stride) under the passes, same hand-counted wait as above.  When the
+// chunk ends on an odd block the imaginary part is zero (zero-byte descriptor) and its spectrum is not stored (ditto).
+template <int LOG2N>
+__global__ __launch_bounds__(FftCfg<LOG2N>::NT, 4) void k_fwd_tp_ps(FwdPairArgs a, const float2 *__restrict__ twb, int run_len)
+{
+    using F = LdsFft<float, LOG2N, -1>;
+    constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, H = P / 2;
+    static_assert(F::radix(0) == 16 && P == 16, "in_index(tid, e) = tid + e * (N / 16)");
+    static_assert(F::phys(32) == 33 && F::phys(N - 1) == N - 1 + N / 32 - 1, "the split step's addresses assume i + (i >> 5)");
+    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS + 1];
+    __shared__ __attribute__((aligned(16))) float2 ldsb[F::LDSB_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int w = xcd_remap();
+    const int C = a.C, units = a.n_eng * C;
+    const int rr = w / units, pp = w - rr * units;                       // run, channel: the channels of a run share an XCD
+    const int g = pp / C, c = pp - g * C;
+    const float sc = 0.5f * a.scale;                                     // the split's 1/2, see k_fwd_pair_ps
+    const int t0 = rr * run_len, t1 = min(a.n_t, t0 + run_len);          // run_len is even
+    if (t0 >= t1) return;
+
+    float2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);
+
+    const float *__restrict__ raw = a.raw + (long)g * a.eng_stride + a.frame_off * C + c;
+    const long hist = (long)g * a.hist_eng_stride + c;
+    const unsigned blk_bytes = (unsigned)L * C * 4u;
+    const unsigned fo = (unsigned)tid * (unsigned)C * 4u;                // lane offset into a block of frames
+    const unsigned estep = (unsigned)NT * C * 4u;                        // bytes between a thread's consecutive samples
+    static_assert(H == 8, "the prefetch statement moves eight samples per thread and block");
+    float prv[H];                                                        // block t - 1, scaled
+    unsigned nb[H], nc[H];                                               // raw samples of blocks t and t + 1, as loaded
+    {
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((t0 == 0) ? a.prev + hist : raw + (long)(t0 - 1) * L * C, blk_bytes);
+#pragma unroll
+        for (int e = 0; e < H; e++) prv[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, fo, e * estep, 0)) * sc;
+        if (a.n_t == 1) {                                                // one-block chunk: the other history block moves on unchanged
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.carry + hist, blk_bytes), rp = make_rsrc(a.save_prev + hist, blk_bytes);
+#pragma unroll
+            for (int e = 0; e < H; e++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_raw_buffer_load_b32(rc, fo, e * estep, 0), rp, fo, e * estep, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(raw + (long)t0 * L * C, blk_bytes);
+        const __amdgpu_buffer_rsrc_t rn = make_rsrc(raw + (long)(t0 + 1) * L * C, t0 + 1 < t1 ? blk_bytes : 0u);
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            nb[e] = __builtin_amdgcn_raw_buffer_load_b32(rb, fo, e * estep, 0);
+            nc[e] = __builtin_amdgcn_raw_buffer_load_b32(rn, fo, e * estep, 0);
+        }
+        // consumed before the loop, so inside it the compiler has no pending load of its own to wait for
+#pragma unroll
+        for (int e = 0; e < H; e++) asm volatile("" : "+v"(nb[e]), "+v"(nc[e]));
+    }
+    float *__restrict__ da0 = a.dst + (long)(g * C + c) * a.dst_ch_stride;
+    for (int t = t0; t < t1; t += 2) {
+        float re[P], im[P];
+        // blocks t, t + 1 have landed when all but the 2 (P/4) spectrum stores issued after their prefetch are done
+        asm_wait_vmcnt<2 * (P / 4)>(nb, nc);
+        if (t + 1 >= a.n_t - 2) {                                        // uniform: one of the chunk's last two blocks is here
+            // the engine's history: the raw samples of the last two blocks of the chunk (stores only, outside the
+            // window the counted wait spans)
+            if (t >= a.n_t - 2) {
+                const __amdgpu_buffer_rsrc_t rk = make_rsrc((t == a.n_t - 1 ? a.save_last : a.save_prev) + hist, blk_bytes);
+#pragma unroll
+                for (int e = 0; e < H; e++) __builtin_amdgcn_raw_buffer_store_b32(nb[e], rk, fo, e * estep, 0);
+            }
+            if (t + 1 < a.n_t) {
+                const __amdgpu_buffer_rsrc_t rk = make_rsrc((t + 1 == a.n_t - 1 ? a.save_last : a.save_prev) + hist, blk_bytes);
+#pragma unroll
+                for (int e = 0; e < H; e++) __builtin_amdgcn_raw_buffer_store_b32(nc[e], rk, fo, e * estep, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const float vb = __uint_as_float(nb[e]) * sc, vc = __uint_as_float(nc[e]) * sc;
+            re[e] = prv[e]; im[e] = vb;                                  // windows [t-1 | t] and [t | t+1]
+            re[H + e] = vb; im[H + e] = vc;
+            prv[e] = vc;
+        }
+        {
+            float2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+            if constexpr (S == 1) {
+                // blocks t + 2 and t + 3 under the remaining passes; past the end of the run the descriptors have
+                // zero bytes and the loads return zeros (no branch)
+                asm_prefetch2x8x1(nb, nc, fo, make_rsrc_words(raw + (long)(t + 2) * L * C, t + 2 < t1 ? blk_bytes : 0u),
+                                  make_rsrc_words(raw + (long)(t + 3) * L * C, t + 3 < t1 ? blk_bytes : 0u), estep);
+            }
+        });
+
+        // Z in natural order to LDS, then two-for-one split (k_fwd_pair_ps)
+        int tz = tid; asm volatile("" : "+v"(tz));
+        __syncthreads();
+        {
+            float2 *zw = lds + F::phys(tz);
+            static_for<0, P>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                static_assert(F::out_index(0, e) % 32 == 0, "additive padding");
+                float2 v; v.x = re[e]; v.y = im[e];
+                zw[F::phys(F::out_index(0, e))] = v;
+            });
+        }
+        __syncthreads();
+        const long slot_a = (long)((a.base_slot + t) % a.ring) * N, slot_b = (long)((a.base_slot + t + 1) % a.ring) * N;
+        const __amdgpu_buffer_rsrc_t rxa = make_rsrc(da0 + slot_a, (unsigned)N * 4u);
+        const __amdgpu_buffer_rsrc_t rxb = make_rsrc(da0 + slot_b, t + 1 < a.n_t ? (unsigned)N * 4u : 0u);   // odd end: dropped
+        const float2 *zk = lds + F::phys(2 * tz);
+        constexpr int OMAX = F::phys(2 * NT * (P / 4 - 1));
+        const float2 *zn1 = lds + (F::phys(N - 1 - 2 * tz) - OMAX);
+        const float2 *zn0 = zn1 + ((tz & 15) == 0 ? 2 : 1);
+#pragma unroll
+        for (int j = 0; j < P / 4; j++) {
+            if (j > 0) __builtin_amdgcn_sched_barrier(0);
+            const int o = F::phys(2 * NT * j);
+            const float2 zk0 = zk[o], zk1 = zk[o + 1];
+            const float2 zn0v = zn0[OMAX - o], zn1v = zn1[OMAX - o];
+            float4 xa, xb;
+            xa.x = zk0.x + zn0v.x; xa.y = zk0.y - zn0v.y;
+            xb.x = zk0.y + zn0v.y; xb.y = zn0v.x - zk0.x;
+            xa.z = zk1.x + zn1v.x; xa.w = zk1.y - zn1v.y;
+            xb.z = zk1.y + zn1v.y; xb.w = zn1v.x - zk1.x;
+            if (j == 0) {                                                // bin 0 is DC | Nyquist, both real
+                const float2 zh = lds[F::phys(L)];
+                const bool k0 = tz == 0;
+                xa.x = k0 ? 2.f * zk0.x : xa.x; xa.y = k0 ? 2.f * zh.x : xa.y;
+                xb.x = k0 ? 2.f * zk0.y : xb.x; xb.y = k0 ? 2.f * zh.y : xb.y;
+            }
+            buf_store4<(BFIR_NT_X & 1) ? 2 : 0>(rxa, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xa);
+            buf_store4<(BFIR_NT_X & 1) ? 2 : 0>(rxb, (unsigned)tz * 16u, (unsigned)(j * NT) * 16u, xb);
+        }
+    }
+    // the last prefetch (zero-byte descriptors) is still in flight and will write nb / nc: see k_fwd_pair_ps
+    asm_wait_vmcnt<0>(nb, nc);
+}
+
 // ---- persistent inverse kernel ---------------------------------------------------------------------
 // The same treatment for the way back: one workgroup turns a run of consecutive product spectra of one
 // channel pair into output frames.  The next block's two spectra (64 KiB per workgroup) are fetched into
@@ -648,6 +832,149 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, inv_ps_min_waves<LOG2N>()) void 
     }
 }
 
+// ---- persistent inverse kernel, pairs in TIME --------------------------------------------------------------
+// Z = Y_t + i Y_{t+1} of ONE channel: Re z is block t's output, Im z block t + 1's (k_fwd_tp_ps).  4-byte samples at
+// the frame stride, 16 stores per transform (hence the wait for all but 16), both blocks' overflow statistics go to
+// the one channel; at an odd chunk end Y_{t+1} reads as zero and its samples are not stored (zero-byte descriptors).
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float f)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(f), r, voff, soff, 0);
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(FftCfg<LOG2N>::NT, inv_ps_min_waves<LOG2N>()) void k_inv_tp_ps(InvPairArgs a, const float2 *__restrict__ twb, int run_len)
+{
+    using F = LdsFft<float, LOG2N, +1>;
+    constexpr int N = F::M, NT = F::NT, P = F::P, L = N / 2, Q = P / 4;
+    __shared__ __attribute__((aligned(16))) float2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) float2 ldsb[F::LDSB_ELEMS];
+    __shared__ unsigned int red_max[NT / 64 > 0 ? NT / 64 : 1][2], red_cnt[NT / 64 > 0 ? NT / 64 : 1][2];
+
+    const int tid = threadIdx.x;
+    const int w = xcd_remap();
+    const int C = a.C, units = a.n_eng * C;
+    const int rr = w / units, pp = w - rr * units;
+    const int g = pp / C, c = pp - g * C;
+    const int gc = g * C + c;
+    const int t0 = rr * run_len, t1 = min(a.n_t, t0 + run_len);          // run_len is even
+    if (t0 >= t1) return;
+
+    float2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);
+
+    const float *__restrict__ ya0 = a.y + (long)gc * a.y_ch_stride;
+    float *__restrict__ out0 = a.raw + (long)g * a.eng_stride + a.frame_off * C + c;
+    const unsigned blk_bytes = (unsigned)L * C * 4u;
+    const unsigned cio = (unsigned)C;                                    // floats between a channel's consecutive samples
+    static_assert(Q == 4, "the prefetch statement moves four 16-byte pieces per thread and spectrum");
+    u32x4 qa[Q], qb[Q];
+    {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(ya0 + (long)BFIR_YSLOT(a, t0) * N, (unsigned)N * 4u);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(ya0 + (long)BFIR_YSLOT(a, t0 + 1) * N, t0 + 1 < t1 ? (unsigned)N * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < Q; j++) {
+            qa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, (BFIR_NT_Y & 2) ? 2 : 0);
+            qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)tid * 16u, (unsigned)(j * NT) * 16u, (BFIR_NT_Y & 2) ? 2 : 0);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; j++) asm volatile("" : "+v"(qa[j]), "+v"(qb[j]));
+    }
+    const float rmax = a.max;
+    float pk0 = 0.f, pk1 = 0.f;
+    unsigned int c0 = 0u, c1 = 0u;
+    int bad = 0x7fffffff;
+    for (int t = t0; t < t1; t += 2) {
+        int ts = tid; asm volatile("" : "+v"(ts));
+        // the two spectra have landed when all but the P output stores issued after their prefetch are done
+        asm_wait_vmcnt<P>(qa, qb);
+        __syncthreads();                                                 // the previous transform's readers are done
+        {
+            u32x4 *l4 = (u32x4 *)lds;
+#pragma unroll
+            for (int j = 0; j < Q; j++) { l4[ts + j * NT] = qa[j]; l4[L / 2 + ts + j * NT] = qb[j]; }
+        }
+        __syncthreads();
+        // Z[k] = Ya[k] + i Yb[k], Hermitian-extended to the full circle (k_inv_pair_ps)
+        float re[P], im[P];
+        static_for<0, P>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            constexpr int base = F::in_index(0, e);
+            static_assert(base + NT <= L || base >= L, "a thread's points do not straddle L");
+            const int k = base + ts;
+            const int kk = (base < L) ? k : N - k;
+            const bool edge = (base == 0 || base == L) && ts == 0;
+            const float2 pa = lds[edge ? 0 : kk], pb = lds[L + (edge ? 0 : kk)];
+            float zr, zi;
+            if (base < L) { zr = pa.x - pb.y; zi = pa.y + pb.x; }
+            else          { zr = pa.x + pb.y; zi = pb.x - pa.y; }
+            if (base == 0) { zr = edge ? pa.x : zr; zi = edge ? pb.x : zi; }
+            if (base == L) { zr = edge ? pa.y : zr; zi = edge ? pb.y : zi; }
+            re[e] = zr * a.scale; im[e] = zi * a.scale;
+        });
+        pin_registers(re, im);
+        {
+            float2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+            if constexpr (S == 1) {
+                asm_prefetch2x4x4(qa, qb, (unsigned)tl * 16u,
+                                  make_rsrc_words(ya0 + (long)BFIR_YSLOT(a, t + 2) * N, t + 2 < t1 ? (unsigned)N * 4u : 0u),
+                                  make_rsrc_words(ya0 + (long)BFIR_YSLOT(a, t + 3) * N, t + 3 < t1 ? (unsigned)N * 4u : 0u), (unsigned)NT * 16u);
+            }
+        });
+
+        // first L samples are the valid half: Re -> block t, Im -> block t + 1
+        const bool has_b = t + 1 < a.n_t;
+        const __amdgpu_buffer_rsrc_t roa = make_rsrc(out0 + (long)t * L * C, blk_bytes);
+        const __amdgpu_buffer_rsrc_t rob = make_rsrc(out0 + (long)(t + 1) * L * C, has_b ? blk_bytes : 0u);
+        int to = tid; asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int n = F::out_index(to, e);
+            if (F::out_index(0, e) < L) {
+                const float va = re[e], vb = has_b ? im[e] : 0.f;
+                buf_store1(roa, (unsigned)to * cio * 4u, (unsigned)F::out_index(0, e) * cio * 4u, va);
+                buf_store1(rob, (unsigned)to * cio * 4u, (unsigned)F::out_index(0, e) * cio * 4u, vb);
+                c0 += (fabsf(va) > rmax) ? 1u : 0u;
+                c1 += (fabsf(vb) > rmax) ? 1u : 0u;
+                pk0 = fmaxf(pk0, fabsf(va)); pk1 = fmaxf(pk1, fabsf(vb));
+                // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+                if (F::out_index(0, e) == 0) {
+                    const bool na = n == 0 && !isfinite(va), nbb = n == 0 && has_b && !isfinite(vb);
+                    bad = (na && t < bad) ? t : bad;
+                    bad = (nbb && t + 1 < bad) ? t + 1 : bad;
+                }
+            }
+        }
+    }
+    asm_wait_vmcnt<0>(qa, qb);                                           // see k_inv_pair_ps
+    if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
+    unsigned int mx0 = __float_as_uint(fmaxf(pk0, pk1)), mx1 = 0u;       // one channel: its peak over both blocks
+    c0 += c1; c1 = 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int m0 = __shfl_xor(mx0, o);
+        mx0 = m0 > mx0 ? m0 : mx0;
+        c0 += __shfl_xor(c0, o);
+    }
+    if ((tid & 63) == 0) { red_max[tid >> 6][0] = mx0; red_cnt[tid >> 6][0] = c0; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int m = 0u, n = 0u;
+        for (int wv = 0; wv < (NT + 63) / 64; wv++) { m = red_max[wv][0] > m ? red_max[wv][0] : m; n += red_cnt[wv][0]; }
+        DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + gc;
+        if (n) atomicAdd(&of->n_overflows, n);
+        if ((unsigned long long)m > *(volatile unsigned long long *)&of->largest_bits)
+            atomicMax(&of->largest_bits, (unsigned long long)m);
+    }
+    (void)mx1;
+}
+
 }  // namespace
 
 #define BFIR_FOR_PAIR_LOG2N(F) F(10) F(11) F(12) F(13) F(14)
@@ -678,6 +1005,17 @@ void launch_fwd_pair(const FftPlan &plan, const FwdPairArgs &a_, hipStream_t s)
 #ifdef BFIR_EXPERIMENT_ALIAS
     if (const int xa = bfir_alias_env("BFIR_X_ALIAS")) { a.ring = xa; a.base_slot %= xa; }
 #endif
+    if (a.tp) {                                            // pairs in time: one unit per channel, runs of an even number of blocks
+        const int units = a.n_eng * a.C;
+        if (a.n_t <= 0 || units <= 0 || !plan.twb) return;
+        const int len = std::max(2, pair_run_len(a.n_t, units, false) & ~1), runs = (a.n_t + len - 1) / len;
+        switch (plan.log2m) {
+#define F(lg) case lg: hipLaunchKernelGGL((k_fwd_tp_ps<lg>), dim3(runs * units), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.twb, len); break;
+            BFIR_FOR_PAIR_LOG2N(F)
+#undef F
+        }
+        return;
+    }
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
     const char *pe = getenv("BFIR_PAIR_PERSIST");
@@ -704,6 +1042,17 @@ void launch_inv_pair(const FftPlan &plan, const InvPairArgs &a_, hipStream_t s)
 #ifdef BFIR_EXPERIMENT_ALIAS
     if (const int ya = bfir_alias_env("BFIR_Y_ALIAS")) a.y_alias = ya;
 #endif
+    if (a.tp) {                                            // pairs in time (k_inv_tp_ps)
+        const int units = a.n_eng * a.C;
+        if (a.n_t <= 0 || units <= 0 || !plan.twb) return;
+        const int len = std::max(2, pair_run_len(a.n_t, units, true) & ~1), runs = (a.n_t + len - 1) / len;
+        switch (plan.log2m) {
+#define F(lg) case lg: hipLaunchKernelGGL((k_inv_tp_ps<lg>), dim3(runs * units), dim3(FftCfg<lg>::NT), 0, s, a, (const float2 *)plan.twb, len); break;
+            BFIR_FOR_PAIR_LOG2N(F)
+#undef F
+        }
+        return;
+    }
     const int items = a.n_t * a.n_eng * (a.C / 2);
     if (items <= 0) return;
     const char *pe = getenv("BFIR_PAIR_PERSIST");

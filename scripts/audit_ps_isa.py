@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Machine check of the hand-counted vmcnt scheme of the persistent pair kernels (pair.hip).
 
-k_fwd_pair_ps / k_inv_pair_ps issue the next block's buffer loads from an inline-asm statement the compiler's
+k_fwd_pair_ps / k_inv_pair_ps (and their pairs-in-time siblings k_fwd_tp_ps / k_inv_tp_ps) issue the next block's buffer loads from an inline-asm statement the compiler's
 s_waitcnt bookkeeping cannot see, and wait for them with a hand-written `s_waitcnt vmcnt(N)`, N = the vector-memory
 stores issued after the prefetch.  That is only right while, in the code hipcc actually emits,
 
@@ -93,8 +93,8 @@ def audit_kernel(k, meta):
     if not pre:
         return ["no inline-asm prefetch found"]
     # one statement = consecutive asm loads
-    if pre[-1] - pre[0] != len(pre) - 1 or len(pre) != 8:
-        errs.append("expected ONE prefetch statement of 8 loads, found asm loads at %s" % pre)
+    if pre[-1] - pre[0] != len(pre) - 1 or len(pre) not in (8, 16):
+        errs.append("expected ONE prefetch statement of 8 (or, pairs in time, 16) loads, found asm loads at %s" % pre)
     counted = [w for w in waits if w[1] > 0]
     closing = [w for w in waits if w[1] == 0]
     if len(counted) != 1 or len(closing) != 1:
@@ -148,7 +148,7 @@ def parse(asm_path):
     text = open(asm_path).read().splitlines()
     kernels, cur, name = {}, None, None
     for ln in text:
-        m = re.match(r"^(_ZN4bfir\S*k_(?:fwd|inv)_pair_psILi\d+E\S*):", ln)
+        m = re.match(r"^(_ZN4bfir\S*k_(?:fwd|inv)_(?:pair|tp)_psILi\d+E\S*):", ln)
         if m:
             name, cur = m.group(1), []
             continue
@@ -174,8 +174,8 @@ def audit(asm_path):
     kernels, meta = parse(asm_path)
     report = {}
     for name, k in sorted(kernels.items()):
-        short = re.search(r"k_(fwd|inv)_pair_psILi(\d+)E", name)
-        report["k_%s_pair_ps<%s>" % short.groups()] = audit_kernel(k, meta.get(name, {}))
+        short = re.search(r"k_(fwd|inv)_(pair|tp)_psILi(\d+)E", name)
+        report["k_%s_%s_ps<%s>" % short.groups()] = audit_kernel(k, meta.get(name, {}))
     return report
 
 

@@ -25,7 +25,7 @@ def listing(tmp_path_factory):
 
 def test_persistent_pair_kernels_pass_the_audit(listing):
     rep = audit_ps_isa.audit(listing)
-    assert len(rep) == 10, sorted(rep)                       # forward and inverse, N = 2^10 .. 2^14
+    assert len(rep) == 20, sorted(rep)                       # forward and inverse, channel pairs and time pairs, N = 2^10 .. 2^14
     assert all(not errs for errs in rep.values()), {k: v for k, v in rep.items() if v}
 
 

@@ -153,3 +153,73 @@ def test_automatic_chunk_equals_explicit_chunks(orc, bfir):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     ref = orc.Engine(L, B, 4, C); ref.set_coeff(h)
     assert rel_err(outs[0], ref.run(x)[1]) <= TOL[4]
+
+
+# ---- pairs in TIME: odd channel counts and single channels on the float fast path (k_fwd_tp_ps / k_inv_tp_ps) -----------
+# Blocks t and t + 1 of ONE channel are the real and the imaginary part of a transform, so the fast path no longer
+# needs an even channel count.  Which blocks share a transform depends on where a launch starts,
+# so results of different launch cuts agree to rounding (the 2e-6 the two FFT factorisations differ by), not bit for bit.
+@pytest.mark.parametrize("L,B,C,nb,chunk", [(512, 3, 1, 9, 4), (1024, 5, 3, 13, 1), (4096, 2, 7, 6, 3), (4096, 32, 1, 70, 16),
+                                            (8192, 2, 1, 5, 2), (2048, 4, 5, 11, 64), (1024, 6, 3, 12, 5)])
+def test_time_paired_path_matches_oracle_and_planar_path(orc, bfir, L, B, C, nb, chunk):
+    h, x = _data(orc, C, B * L - 11, nb * L, seed=L + C)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    outs = []
+    for make in (bfir.Brutefir, lambda *a: _planar_engine(bfir, *a)):
+        eng = make(L, B, 4, C); eng.set_chunk(chunk); assert eng.set_coeff(h) == 0
+        rc, y = eng.run(x)
+        assert rc == 0 and rel_err(y, y_ref) <= TOL[4]
+        outs.append((y, [eng.overflow(c) for c in range(C)]))
+        eng.close()
+    assert rel_err(outs[0][0], outs[1][0]) <= 2e-6
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert a.n_overflows == b.n_overflows and abs(a.largest - b.largest) <= 1e-5 * max(b.largest, 1e-30)
+
+
+def test_time_paired_path_is_the_default_for_odd_channel_counts(orc, bfir):
+    """BFIR_PAIR_TIME=0 keeps such engines on the general path; the two agree to rounding, and differ in the last
+    bits (which is how this test knows the fast path ran)."""
+    L, B, C, nb = 1024, 4, 3, 16
+    h, x = _data(orc, C, B * L - 5, nb * L, seed=77)
+    a = bfir.Brutefir(L, B, 4, C); a.set_coeff(h); _, ya = a.run(x)
+    os.environ["BFIR_PAIR_TIME"] = "0"
+    try:
+        b = bfir.Brutefir(L, B, 4, C)
+    finally:
+        del os.environ["BFIR_PAIR_TIME"]
+    b.set_coeff(h); _, yb = b.run(x)
+    assert rel_err(ya, yb) <= 2e-6 and not np.array_equal(ya, yb)
+
+
+def test_time_paired_history_across_calls_chunks_and_reset(orc, bfir):
+    """One-block calls (every chunk a single block paired with nothing), odd and even call lengths, reset()."""
+    L, B, C = 512, 3, 3
+    h, x = _data(orc, C, 1300, 23 * L, seed=22)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h)
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_coeff(h); eng.set_chunk(4)
+    pos = 0
+    for k, nblk in enumerate((3, 1, 1, 2, 5, 1, 4, 6)):
+        seg = x[pos * L:(pos + nblk) * L]; pos += nblk
+        _, yr = ref.run(seg); rc, y = eng.run(seg)
+        assert rc == 0 and rel_err(y, yr) <= TOL[4], (k, nblk)
+        if k in (2, 5):
+            ref.reset(); eng.reset()
+
+
+def test_time_paired_overflow_statistics_and_nan_verdict(orc, bfir):
+    L, B, C, nb = 512, 2, 3, 9
+    rng = np.random.default_rng(11)
+    h = [np.r_[np.float32(g), np.zeros(700, np.float32)] for g in (0.5, 3.0, 0.25)]   # pure gains
+    x = orc.synth_audio(rng, nb * L, C, np.float32)
+    ref = orc.Engine(L, B, 4, C); ref.set_coeff(h); _, y_ref = ref.run(x)
+    eng = bfir.Brutefir(L, B, 4, C); eng.set_coeff(h); eng.set_chunk(4); rc, y = eng.run(x)
+    assert rc == 0 and rel_err(y, y_ref) <= TOL[4]
+    assert np.abs(np.abs(y_ref.astype(np.float64)) - 1.0).min() > 1e-5   # nothing sits on the threshold
+    for c in range(C):
+        o, r = eng.overflow(c), ref.overflow(c)
+        assert o.n_overflows == r.n_overflows and abs(o.largest - r.largest) <= 1e-5 * r.largest
+    assert eng.overflow(0).n_overflows == 0 and eng.overflow(1).n_overflows > 0
+    bad = x.copy(); bad[4 * L + 7, 2] = np.nan
+    eng2 = bfir.Brutefir(L, B, 4, C); eng2.set_coeff(h)
+    ref2 = orc.Engine(L, B, 4, C); ref2.set_coeff(h)
+    assert ref2.run(bad)[0] == -1 and eng2.run(bad)[0] == -1

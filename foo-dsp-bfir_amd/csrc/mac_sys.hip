@@ -320,7 +320,15 @@ void launch_mac_sys(const MacArgs &a, hipStream_t s)
     } else {
         if (a.B <= 16) launch_sys<double, 2, 8, 4>(a, s);
         else if (a.B <= 32) launch_sys<double, 2, 16, 4>(a, s);
-        else launch_sys<double, 4, 16, 4>(a, s);
+        else {
+            // prefetch depth in slots: 6 (160 registers, three waves per SIMD) measured best, cfg5 39.7 against 39.2 (4)
+            // and 39.4 (8), the plug-in's shape 43.3 / 40.1 / 43.7 (profiles/r03_fp64.txt); BFIR_SYS_D overrides
+            const char *de = getenv("BFIR_SYS_D");
+            const int d = de ? atoi(de) : 6;
+            if (d >= 8) launch_sys<double, 4, 16, 8>(a, s);
+            else if (d == 6) launch_sys<double, 4, 16, 6>(a, s);
+            else launch_sys<double, 4, 16, 4>(a, s);
+        }
     }
 }
 

@@ -29,6 +29,29 @@ def bfir():
     return b
 
 
+class env_override:
+    """Set environment switches the library reads at engine creation / per launch and put back what was there before --
+    a switch given to the whole run (scripts/gpu_env_matrix.sh) must survive a test that flips it for one engine."""
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def rel_err(y, ref):
     """max |y - ref| / max |ref|: the norm the 1e-5 / 1e-12 tolerances are stated in."""
     y = np.asarray(y, dtype=np.float64)

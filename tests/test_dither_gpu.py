@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import env_override
+
 from test_oracle_dither import _taus_table
 
 pytestmark = pytest.mark.gpu
@@ -76,11 +78,8 @@ def test_cbuf2raw_dither_needs_the_instance(bfir):
 
 
 def _planar(bfir, *a, **kw):
-    os.environ["BFIR_PAIR"] = "0"
-    try:
+    with env_override(BFIR_PAIR="0"):
         return bfir.Brutefir(*a, **kw)
-    finally:
-        del os.environ["BFIR_PAIR"]
 
 
 class _OracleDither:

@@ -5,7 +5,7 @@ the figures BASELINE.json's north_star states."""
 import numpy as np
 import pytest
 
-from conftest import TOL, rel_err
+from conftest import TOL, env_override, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -278,11 +278,8 @@ def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, i
     x = (orc.synth_audio(rng, nb * L, C, np.float64) * 1.7).astype(orc.fmt_dtype(in_fmt))   # some samples overflow 1.0
     outs = []
     for direct in (True, False):
-        os.environ["BFIR_DIRECT"] = "1" if direct else "0"   # 1 forces it where the engine would not pick it itself
-        try:
+        with env_override(BFIR_DIRECT="1" if direct else "0"):   # 1 forces it where the engine would not pick it itself
             eng = bfir.Brutefir(L, B, s, C, in_fmt, out_fmt)
-        finally:
-            os.environ.pop("BFIR_DIRECT", None)
         eng.set_chunk(4)
         assert eng.set_coeff(h, scale=12.0) == 0
         parts = [eng.run(x[a * L:b * L])[1] for a, b in ((0, 6), (6, 7), (7, nb))]
@@ -315,12 +312,8 @@ def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
     d_x[pad:pad + x.size] = torch.from_numpy(x.reshape(-1)).cuda()
     outs = []
     for direct in (None, "0"):
-        if direct is not None:
-            os.environ["BFIR_DIRECT"] = direct
-        try:
+        with env_override(**({} if direct is None else {"BFIR_DIRECT": direct})):
             eng = bfir.Brutefir(L, B, 8, C, 8, 8, n_engines=ne)
-        finally:
-            os.environ.pop("BFIR_DIRECT", None)
         eng.set_chunk(4)
         for g in range(ne):
             assert eng.set_coeff(hs[g], engine_index=g) == 0
@@ -351,9 +344,7 @@ def test_small_launch_mac_kernel_gives_the_bits_of_the_throughput_kernels(orc, b
     x = orc.synth_audio(rng, nb * L, C, orc.real_dtype(s))
     outs = []
     for mode in ("small", "no_small", "one_launch"):
-        if mode == "no_small":
-            os.environ["BFIR_NO_MAC_SMALL"] = "1"; os.environ["BFIR_NO_BOUNCE"] = "1"
-        try:
+        with env_override(**({"BFIR_NO_MAC_SMALL": "1", "BFIR_NO_BOUNCE": "1"} if mode == "no_small" else {})):
             eng = bfir.Brutefir(L, B, s, C)
             assert eng.set_coeff(h) == 0
             if mode == "one_launch":
@@ -364,8 +355,6 @@ def test_small_launch_mac_kernel_gives_the_bits_of_the_throughput_kernels(orc, b
                 parts = [eng.run(x[a * L:b * L])[1] for a, b in zip(cuts[:-1], cuts[1:])]
             outs.append(np.concatenate(parts))
             eng.close()
-        finally:
-            os.environ.pop("BFIR_NO_MAC_SMALL", None); os.environ.pop("BFIR_NO_BOUNCE", None)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     ref = orc.Engine(L, B, s, C); ref.set_coeff(h)
     assert rel_err(outs[0], ref.run(x)[1]) <= TOL[s]
@@ -383,16 +372,12 @@ def test_fp64_mac_variants_give_identical_bits(orc, bfir, variant):
     x = orc.synth_audio(rng, nb * L, C, np.float64)
     outs = []
     for v in (None, variant):
-        if v is not None:
-            os.environ["BFIR_MAC64_VARIANT"] = v
-        try:
+        with env_override(**({} if v is None else {"BFIR_MAC64_VARIANT": v})):
             eng = bfir.Brutefir(L, B, 8, C)
             eng.set_chunk(nb)
             assert eng.set_coeff(h) == 0
             outs.append(eng.run(x)[1])
             eng.close()
-        finally:
-            os.environ.pop("BFIR_MAC64_VARIANT", None)
     assert np.array_equal(outs[0], outs[1])
     ref = orc.Engine(L, B, 8, C); ref.set_coeff(h)
     assert rel_err(outs[0], ref.run(x)[1]) <= TOL[8]

@@ -10,17 +10,14 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TOL, rel_err
+from conftest import TOL, env_override, rel_err
 
 pytestmark = pytest.mark.gpu
 
 
 def _planar_engine(bfir, *args, **kw):
-    os.environ["BFIR_PAIR"] = "0"
-    try:
+    with env_override(BFIR_PAIR="0"):
         return bfir.Brutefir(*args, **kw)
-    finally:
-        del os.environ["BFIR_PAIR"]
 
 
 def _data(orc, C, taps, frames, seed):
@@ -122,16 +119,10 @@ def test_more_partitions_than_one_register_batch(orc, bfir, L, B, C, nb, chunk):
     eng2 = bfir.Brutefir(L, B, 4, C); eng2.set_chunk(nb); eng2.set_coeff(h)
     assert np.array_equal(eng2.run(x)[1], y)
     # and the batched sums are the very sums of the grouped-layout MAC kernels (general path for both)
-    os.environ["BFIR_PAIR"] = "0"
-    try:
+    with env_override(BFIR_PAIR="0"):
         a = bfir.Brutefir(L, B, 4, C)
-        os.environ["BFIR_MAC_VARIANT"] = "8"
-        try:
+        with env_override(BFIR_MAC_VARIANT="8"):
             b = bfir.Brutefir(L, B, 4, C)
-        finally:
-            del os.environ["BFIR_MAC_VARIANT"]
-    finally:
-        del os.environ["BFIR_PAIR"]
     for e in (a, b):
         e.set_chunk(chunk); e.set_coeff(h)
     assert np.array_equal(a.run(x)[1], b.run(x)[1])
@@ -179,14 +170,13 @@ def test_time_paired_path_matches_oracle_and_planar_path(orc, bfir, L, B, C, nb,
 def test_time_paired_path_is_the_default_for_odd_channel_counts(orc, bfir):
     """BFIR_PAIR_TIME=0 keeps such engines on the general path; the two agree to rounding, and differ in the last
     bits (which is how this test knows the fast path ran)."""
+    if any(os.environ.get(k) for k in ("BFIR_PAIR", "BFIR_PAIR_PERSIST", "BFIR_PAIR_TIME")):
+        pytest.skip("a path-selecting switch is set for the whole run (scripts/gpu_env_matrix.sh)")
     L, B, C, nb = 1024, 4, 3, 16
     h, x = _data(orc, C, B * L - 5, nb * L, seed=77)
     a = bfir.Brutefir(L, B, 4, C); a.set_coeff(h); _, ya = a.run(x)
-    os.environ["BFIR_PAIR_TIME"] = "0"
-    try:
+    with env_override(BFIR_PAIR_TIME="0"):
         b = bfir.Brutefir(L, B, 4, C)
-    finally:
-        del os.environ["BFIR_PAIR_TIME"]
     b.set_coeff(h); _, yb = b.run(x)
     assert rel_err(ya, yb) <= 2e-6 and not np.array_equal(ya, yb)
 

@@ -284,12 +284,13 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         e->pair_tp = e->pair_tp && e->pair;
         const char *dv = getenv("BFIR_DIRECT");
         // worth it where a channel's samples are 8 bytes apart or wider units: FLOAT64 frames (any C), or one
-        // channel (contiguous samples), or stereo float frames (the reference plug-in's own shape), which k_fwd /
-        // k_inv move as whole frames with both channels in one workgroup.  Other 4-byte samples at a stride
+        // channel (contiguous samples), or float frames with an even channel count (the reference plug-in's own shape:
+        // fp64 arithmetic, float32 frames), which k_fwd / k_inv move a channel PAIR at a time with both channels in one
+        // workgroup (stereo: two whole frames per lane; wider frames since round 3: 33.5 -> ~40 Gsamples/s at 4-8 channels).  Other 4-byte samples at a stride
         // (float frames, C > 2) are faster through the staging kernels (profiles/r02_other_configs.txt: one
         // channel per workgroup ran the plug-in's shape at 11.4 instead of 20.6 Gsamples/s).  BFIR_DIRECT=1
         // forces it (tests).
-        const bool stereo = e->in_bytes == 4 && e->out_bytes == 4 && channels == 2 && !e->ilv &&
+        const bool stereo = e->in_bytes == 4 && e->out_bytes == 4 && (channels % 2) == 0 && !e->ilv &&
                             direct_stereo_supported(filter_length, realsize);
         const bool wide = (e->in_bytes == 8 && e->out_bytes == 8) || channels == 1 || stereo;
         e->direct = !e->pair && fmt_is_native(in_format) && fmt_is_native(out_format) && !(pv && atoi(pv) == 0) &&

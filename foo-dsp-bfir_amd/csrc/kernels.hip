@@ -149,10 +149,14 @@ bool direct_stereo_supported(int filter_length, int realsize)
     }
     return ok;
 }
-// float frames of a stereo engine whose blocks start on 16-byte boundaries
+// float frames of an engine with an even channel count: a workgroup takes the two channels of a PAIR.  Stereo frames
+// are moved two at a time (16 bytes per lane: blocks on 16-byte boundaries), wider frames 8 bytes (one pair of one
+// frame) per lane.
 static bool direct_stereo_ok(int raw_bytes, int C, const void *raw, long eng_stride_samples, long frame_off)
 {
-    return raw_bytes == 4 && C == 2 && ((uintptr_t)raw % 16) == 0 && (eng_stride_samples % 4) == 0 && (frame_off % 2) == 0;
+    if (raw_bytes != 4 || C < 2 || (C & 1)) return false;
+    if (C == 2) return ((uintptr_t)raw % 16) == 0 && (eng_stride_samples % 4) == 0 && (frame_off % 2) == 0;
+    return ((uintptr_t)raw % 8) == 0 && (eng_stride_samples % 2) == 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
     T re[P], im[P];
     const T ls = (T)a.load_scale;
     if constexpr (DIRECT && CPW == 2) {
-        // stereo float frames: float4 m of a block = frames 2m, 2m+1 = (l, r, l, r); a.C == 2, 16-byte aligned (launcher)
+      if (a.C == 2) {
+        // stereo float frames: float4 m of a block = frames 2m, 2m+1 = (l, r, l, r); 16-byte aligned (launcher)
         const int g = gc >> 1;
         const long ho = (long)g * a.hist_eng_stride;
         const float4 *__restrict__ rc4 = (const float4 *)((const float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
@@ -217,6 +222,35 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
                     ((float4 *)((float *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho))[m - M / 2] = v;
             }
         }
+      } else {
+        // wider frames, even channel count (round 3): the workgroup's two channels are the pair (c0, c0 + 1) of every
+        // frame, 8 bytes per frame at the frame stride -- the access pattern of the fp32 pair kernels
+        const int C = a.C, g = gc / C, c0 = gc - g * C - half;
+        const long ho = (long)g * a.hist_eng_stride + c0;
+        const float *__restrict__ rc = (const float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c0;
+        const float *__restrict__ ro = (t == 0) ? (const float *)a.prev_raw + ho : rc - (long)M * C;
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int m = F::in_index(tid, e);
+            if (m < M / 2) {                                   // frames 2m, 2m+1 of the previous block
+                const float2 v0 = *(const float2 *)(ro + (long)(2 * m) * C), v1 = *(const float2 *)(ro + (long)(2 * m + 1) * C);
+                re[e] = (T)(half ? v0.y : v0.x) * ls; im[e] = (T)(half ? v1.y : v1.x) * ls;
+                if (a.n_t == 1 && half == 0) {                 // one-block chunk: the other history block moves on unchanged
+                    float *sp = (float *)a.save_prev + ho; const float *cr = (const float *)a.carry + ho;
+                    *(float2 *)(sp + (long)(2 * m) * C) = *(const float2 *)(cr + (long)(2 * m) * C);
+                    *(float2 *)(sp + (long)(2 * m + 1) * C) = *(const float2 *)(cr + (long)(2 * m + 1) * C);
+                }
+            } else {                                           // frames of this block
+                const int n = 2 * m - M;
+                const float2 v0 = *(const float2 *)(rc + (long)n * C), v1 = *(const float2 *)(rc + (long)(n + 1) * C);
+                re[e] = (T)(half ? v0.y : v0.x) * ls; im[e] = (T)(half ? v1.y : v1.x) * ls;
+                if (t >= a.n_t - 2 && half == 0) {             // the engine's history (one half stores the pair)
+                    float *kp = (float *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho;
+                    *(float2 *)(kp + (long)n * C) = v0; *(float2 *)(kp + (long)(n + 1) * C) = v1;
+                }
+            }
+        }
+      }
     } else if constexpr (DIRECT) {
         using RS = typename std::conditional<DIRECT, TR, float>::type;
         const int C = a.C, g = gc / C, c = gc - g * C;
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
             const int m = F::out_index(tid, e);
             if (m < M / 2) {
                 const T v0 = re[e], v1 = im[e];
-                if constexpr (CPW == 2) { stg[4 * m + half] = (float)v0; stg[4 * m + 2 + half] = (float)v1; }
+                if constexpr (CPW == 2) { stg[4 * m + half] = (float)v0; stg[4 * m + 2 + half] = (float)v1; }   // frames 2m, 2m+1: (l, r, l, r)
                 else { out[(long)(2 * m) * C] = (RS)v0; out[(long)(2 * m + 1) * C] = (RS)v1; }
                 // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
                 cnt += ((v0 < (T)0) ? (v0 < rmin) : (v0 > rmax)) ? 1u : 0u;
@@ -468,13 +502,23 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
         }
         if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_cnt[tid >> 6] = cnt; }
         __syncthreads();
-        if constexpr (CPW == 2) {                              // whole frames out: 2 M floats, 16 bytes per lane
-            float4 *__restrict__ out4 = (float4 *)((float *)a.raw + (long)(gc >> 1) * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
-            const float4 *stg4 = (const float4 *)stg;
+        if constexpr (CPW == 2) {
+            if (C == 2) {                                      // whole frames out: 2 M floats, 16 bytes per lane
+                float4 *__restrict__ out4 = (float4 *)((float *)a.raw + (long)(gc >> 1) * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
+                const float4 *stg4 = (const float4 *)stg;
 #pragma unroll
-            for (int j = 0; j < P / 4; j++) {
-                const int idx = (int)threadIdx.x + j * 2 * NT;
-                out4[idx] = stg4[idx];
+                for (int j = 0; j < P / 4; j++) {
+                    const int idx = (int)threadIdx.x + j * 2 * NT;
+                    out4[idx] = stg4[idx];
+                }
+            } else {                                           // the pair's two floats of every frame, at the frame stride
+                float *__restrict__ outp = (float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + (c - half);
+                const float2 *stg2 = (const float2 *)stg;
+#pragma unroll
+                for (int j = 0; j < P / 2; j++) {
+                    const int f = (int)threadIdx.x + j * 2 * NT;   // frame 0 .. M-1
+                    *(float2 *)(outp + (long)f * C) = stg2[f];
+                }
             }
         }
         if (tid == 0) {
@@ -1672,12 +1716,13 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     const int tt = a.n_t;
     if (tt <= BFIR_MAC_SMALL_MAX && !getenv("BFIR_NO_MAC_SMALL")) { launch_mac_small(a, s); return; }   // env: A/B and tests
     {   // The forward-walking systolic kernel (mac_sys.hip: fp32 pairs layout up to 128 partitions, fp64 grouped layout
-        // up to 64): the default for fp64 (cfg5 +12 %, its MAC -20 % against the LDS-tiled kernel) and for fp32 with more
-        // than 32 partitions (+1..5 % against k_mac_lds); with up to 32 partitions k_mac_stream stays ahead (0.49 against
-        // 0.59 ms per 4096 headline blocks: two lanes per bin double the vector-memory instructions per FMA,
-        // profiles/r03_mac_sys.txt).  BFIR_MAC_SYS=1 / 0 forces / forbids it; read per launch (tests switch it in-process).
+        // up to 64): the default for fp64 (cfg5 +14 %, its MAC -20 % against the LDS-tiled kernel) and for fp32 with 33 to
+        // 64 partitions (+1..5 % against k_mac_lds; with eight lanes per bin, 65 to 128 partitions, it is 10 % SLOWER:
+        // 44.7 against 49.6 Gsamples/s at 8 channels x 128 partitions of 1024); with up to 32 partitions k_mac_stream stays
+        // ahead (0.49 against 0.59 ms per 4096 headline blocks: two lanes per bin double the vector-memory instructions
+        // per FMA, profiles/r03_mac_sys.txt).  BFIR_MAC_SYS=1 / 0 forces / forbids it; read per launch (tests switch it).
         const char *ms = getenv("BFIR_MAC_SYS");
-        const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || a.B > 32) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
+        const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || (a.B > 32 && a.B <= 64)) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
         if (want && mac_sys_supported(a) && !getenv("BFIR_MAC_BATCHED")) { launch_mac_sys(a, s); return; }
     }
     if (a.realsize == 4) {

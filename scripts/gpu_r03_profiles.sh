@@ -68,6 +68,9 @@ run plugin_fp64_f32frames --workload plugin_2ch_65536tap_L1024_fp64_f32frames   
 BFIR_MAC_SYS=0 run plugin_fp64_f32frames_r02_mac --workload plugin_2ch_65536tap_L1024_fp64_f32frames
 run plugin_fp64_f32frames_chunk4096 --workload plugin_2ch_65536tap_L1024_fp64_f32frames --chunk 4096
 run plugin_fp64_f64frames --workload plugin_2ch_65536tap_L1024_fp64
+run plugin_fp64_f32frames_8ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 8       # 7.1 audio through the shipped precision
+BFIR_DIRECT=0 run plugin_fp64_f32frames_8ch_staging --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 8
+run plugin_fp64_f32frames_6ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 6
 run plugin_fp32 --workload plugin_2ch_65536tap_L1024_fp32
 run plugin_8ch_B64 --workload plugin_8ch_65536tap_L1024_fp32
 run plugin_8ch_B128 --workload plugin_8ch_131072tap_L1024_fp32
@@ -84,4 +87,5 @@ echo "== two ranks on this one GPU (gloo), both sharding modes" | tee -a $OUT/pr
 timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --device 0 --blocks 32768 --steps 6 --warmup 2 --no-extras --no-cpu-baseline > $OUT/gpus2_replicas.json 2>$OUT/gpus2.err; python -c "import json; d=json.load(open('$OUT/gpus2_replicas.json')); print('replicas', d['n_gpus'], d['scaling'], d['value'])"
 timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --device 0 --shard channels --blocks 32768 --steps 6 --warmup 2 --no-extras --no-cpu-baseline > $OUT/gpus2_channels.json 2>>$OUT/gpus2.err; python -c "import json; d=json.load(open('$OUT/gpus2_channels.json')); print('channels', d['n_gpus'], d['scaling'], d['value'])"
 find $OUT -name "*.db" -delete; find $OUT -size +8M -delete
+timeout -k 10 600 python bench.py --gpus 6 --dist-backend gloo --device 0 --shard channels --blocks 4096 --steps 4 --warmup 1 --no-extras --no-cpu-timing --no-exclusive-pass > $OUT/gpus6_channels.json 2>>$OUT/gpus2.err; python -c "import json; d=json.load(open('$OUT/gpus6_channels.json')); print('six ranks, channel shares 2 2 1 1 1 1', d['n_gpus'], d['scaling'], d['value'], d['parity_rel_err_vs_oracle'])"
 echo "== done" | tee -a $OUT/progress.log

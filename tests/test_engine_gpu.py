@@ -331,6 +331,43 @@ def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
         assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames
 
 
+@pytest.mark.parametrize("C,misalign,L", [(4, 0, 1024), (6, 8, 512), (8, 0, 2048), (8, 4, 1024)])
+def test_wide_float_frames_direct_channel_pairs(orc, bfir, C, misalign, L):
+    """fp64 arithmetic on float32 frames with an even channel count above two (5.1 / 7.1 audio through the plug-in's
+    shipped REALSIZE 8): k_fwd / k_inv take a channel PAIR per workgroup, 8 bytes of every frame at the frame stride
+    (round 3; such engines ran the staging kernels before).  Same bits as the staging path -- one-block and multi-block
+    chunks, call-to-call continuation, a batch of engines, device buffers that are 8-byte aligned (the pair path) or
+    only 4-byte aligned (one channel per workgroup)."""
+    import torch
+    B, nb, ne = 3, 9, 2
+    rng = np.random.default_rng(50 + C + misalign)
+    hs = [orc.synth_ir(rng, C, B * L - 3, np.float64) for _ in range(ne)]
+    x = (orc.synth_audio(rng, ne * nb * L, C, np.float64) * 1.3).astype(np.float32).reshape(ne, nb * L, C)
+    pad = misalign // 4
+    d_x = torch.zeros(x.size + 4, dtype=torch.float32, device="cuda")
+    d_x[pad:pad + x.size] = torch.from_numpy(x.reshape(-1)).cuda()
+    outs, ofs = [], []
+    for direct in (None, "0"):
+        with env_override(**({} if direct is None else {"BFIR_DIRECT": direct})):
+            eng = bfir.Brutefir(L, B, 8, C, 8, 8, n_engines=ne)
+        eng.set_chunk(4)
+        for g in range(ne):
+            assert eng.set_coeff(hs[g], engine_index=g) == 0
+        d_y = torch.zeros(x.size + 4, dtype=torch.float32, device="cuda")
+        stride = nb * L * C * 4
+        for a, b in ((0, 5), (5, 6), (6, nb)):
+            eng.run_device(d_x.data_ptr() + misalign + a * L * C * 4, d_y.data_ptr() + misalign + a * L * C * 4, b - a,
+                           in_stride_bytes=stride, out_stride_bytes=stride)
+        assert eng.sync() == 0
+        outs.append(d_y[pad:pad + x.size].cpu().numpy().reshape(ne, nb * L, C))
+        ofs.append([(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(ne * C)])
+        eng.close()
+    assert np.array_equal(outs[0], outs[1]) and ofs[0] == ofs[1]
+    for g in range(ne):
+        ref = orc.Engine(L, B, 8, C, 8, 8); ref.set_coeff(hs[g])
+        assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames
+
+
 @pytest.mark.parametrize("s,L,B,C", [(4, 1024, 40, 2), (4, 128, 5, 3), (8, 1024, 7, 2), (4, 4096, 9, 8), (8, 64, 3, 1)])
 def test_small_launch_mac_kernel_gives_the_bits_of_the_throughput_kernels(orc, bfir, s, L, B, C):
     """Calls of up to four blocks (the plug-in's pattern is one) run k_mac_small -- one lane per bin walking the

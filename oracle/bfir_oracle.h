@@ -13,7 +13,11 @@
  * FFTW 3.3-beta1 library (only Win32 DLLs are in the tree), so this oracle is
  * not checked against outputs of the reference itself.  What pins it instead:
  * an independent long-double direct-form convolution (orc_direct_conv) and
- * scipy's pocketfft (tests/test_oracle.py).
+ * scipy's pocketfft (tests/test_oracle.py).  The one source file of the path
+ * that does compile here, brutefir/hash.c (the DJB hash that names the cache
+ * WAVs), is built in place by oracle/Makefile's `ref` target into
+ * oracle/_ref/ and pins the host mirrors' hash (tests/golden/
+ * djb_hash_ref.json); no arithmetic of this oracle is pinned by it.
  *
  * Third-party arithmetic restated: FFTW 3.3-beta1 r2r transforms FFTW_R2HC
  * and FFTW_HC2R (call sites brutefir/fftw_convolver.cpp:204-209, 367-372,

@@ -94,16 +94,30 @@ def test_overflow_statistics_and_nan_verdict_on_the_pair_path(orc, bfir):
 
 
 def test_pair_path_needs_8_byte_aligned_frames(bfir):
+    """The float fast path moves a stereo frame as one 8-byte access and refuses frames it cannot; the general path
+    (BFIR_PAIR=0, one sample per access) takes the same buffer and gives the bits of the aligned run."""
     import torch
     L, B, C = 512, 2, 2
-    eng = bfir.Brutefir(L, B, 4, C)
-    eng.set_coeff([np.ones(10, np.float32)] * C)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal(2 * L * C).astype(np.float32))
     buf = torch.zeros(2 * L * C + 2, device="cuda", dtype=torch.float32)
     out = torch.zeros_like(buf)
-    with pytest.raises(bfir.BfirError):
-        eng.run_device(buf.data_ptr() + 4, out.data_ptr(), 1)
-    eng.run_device(buf.data_ptr() + 8, out.data_ptr() + 8, 1)   # aligned: fine
-    assert eng.sync() == 0
+    got = {}
+    for pair in ("1", "0"):
+        with env_override(BFIR_PAIR=pair):
+            for off in (2, 1):                                  # samples: 8-byte aligned, then 4
+                eng = bfir.Brutefir(L, B, 4, C)
+                eng.set_coeff([np.ones(10, np.float32)] * C)
+                buf.zero_(); buf[off:off + 2 * L * C] = x.cuda(); out.zero_()
+                if pair == "1" and off == 1:
+                    with pytest.raises(bfir.BfirError):
+                        eng.run_device(buf.data_ptr() + 4 * off, out.data_ptr() + 4 * off, 2)
+                    continue
+                eng.run_device(buf.data_ptr() + 4 * off, out.data_ptr() + 4 * off, 2)
+                assert eng.sync() == 0
+                got[pair, off] = out[off:off + 2 * L * C].cpu().numpy().copy()
+    assert np.array_equal(got["0", 1], got["0", 2])
+    assert rel_err(got["0", 2], got["1", 2]) <= TOL[4]
 
 
 @pytest.mark.parametrize("L,B,C,nb,chunk", [(1024, 40, 2, 50, 16), (512, 70, 3, 80, 32), (1024, 33, 4, 37, 5)])

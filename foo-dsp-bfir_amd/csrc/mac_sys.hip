@@ -15,8 +15,8 @@
 //
 // In slot t stage 0 starts y[t]'s chain from zero and runs its first PL links; stage j continues the chain of y[t - j]
 // from the partial sum stage j-1 finished one slot earlier; stage S-1 finishes y[t - S + 1] and stores it.  Values move
-// one lane up by DPP (row_shr:1 -- an ordinary vector instruction; a first build split a bin across the two HALVES of a
-// wave and paid 5-6 FMA slots per v_permlane32_swap, profiles/r03_fusion_bound.txt): the partial sum (stage j -> j+1),
+// one stage up by DPP (row_shr -- an ordinary vector instruction, see SysLanes; a first build split a bin across the two
+// HALVES of a wave and paid 5-6 FMA slots per v_permlane32_swap, profiles/r03_fusion_bound.txt): the partial sum (stage j -> j+1),
 // and the delay-line value stage j drops from its window, which is exactly stage j+1's newest value of the next slot, so
 // only stage 0 ever reads the delay line from memory.  Every output is ONE chain p = 0 .. S PL - 1 with the fma sequence
 // of every other MAC kernel here: bit-identical sums.  Partitions >= nblk hold h = 0 (an exact no-op).
@@ -91,15 +91,45 @@ template <typename T, int AUX> __device__ __forceinline__ void sys_store(__amdgp
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// the value of the lane below (row_shr:1; lane 0 of a 16-lane row keeps its own: that lane is always a stage 0)
-__device__ __forceinline__ float from_below(float v)
+// Which lane is which stage: the stages of a bin sit 16 / S lanes apart inside a 16-lane DPP row (stage-major: the first
+// 16 / S lanes of a row are stage 0 of its 16 / S bins), so "from the stage below" is row_shr:(16 / S) and the two selects
+// of the exchange come for free from the DPP controls: without bound_ctrl a lane whose source lies outside the row -- a
+// stage 0 -- is not written and keeps the value it loaded itself; with bound_ctrl it reads zero, the start of a chain.
+// One v_mov_b32_dpp per exchanged register and nothing else.  (The first build had the stages in ADJACENT lanes, row_shr:1,
+// and paid a v_cndmask per register or an exec-mask round trip on top: cfg5's MAC 1.64 -> 1.55 ms, profiles/r03_mac_sys.txt.)
+template <int S> struct SysLanes {
+    static_assert(S >= 2 && S <= 16 && (S & (S - 1)) == 0, "stages per bin");
+    static constexpr int BPR = 16 / S;                           // bins per row
+    static constexpr int SHR = 0x110 + BPR;                      // dpp_ctrl row_shr:BPR
+    static __device__ __forceinline__ int stage(int tid) { return (tid & 15) / BPR; }
+    // bin inside the workgroup's column of 256 / S bins
+    static __device__ __forceinline__ int bin(int tid) { return (tid >> 4) * BPR + (tid & (BPR - 1)); }
+};
+
+// stage 0 ? own : v of the stage below
+template <int S> __device__ __forceinline__ unsigned relay1(unsigned own, unsigned v)
 {
-    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(v), __float_as_uint(v), 0x111, 0xf, 0xf, false));
+    return __builtin_amdgcn_update_dpp(own, v, SysLanes<S>::SHR, 0xf, 0xf, false);
 }
-__device__ __forceinline__ double from_below(double v)
+// stage 0 ? 0 : v of the stage below
+template <int S> __device__ __forceinline__ unsigned hand1(unsigned v)
 {
-    const unsigned lo = __builtin_amdgcn_update_dpp((unsigned)__double2loint(v), (unsigned)__double2loint(v), 0x111, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(v, v, SysLanes<S>::SHR, 0xf, 0xf, true);
+}
+template <int S> __device__ __forceinline__ float relay_t(float own, float v)
+{
+    return __uint_as_float(relay1<S>(__float_as_uint(own), __float_as_uint(v)));
+}
+template <int S> __device__ __forceinline__ double relay_t(double own, double v)
+{
+    const unsigned lo = relay1<S>((unsigned)__double2loint(own), (unsigned)__double2loint(v));
+    const unsigned hi = relay1<S>((unsigned)__double2hiint(own), (unsigned)__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int S> __device__ __forceinline__ float hand_t(float v) { return __uint_as_float(hand1<S>(__float_as_uint(v))); }
+template <int S> __device__ __forceinline__ double hand_t(double v)
+{
+    const unsigned lo = hand1<S>((unsigned)__double2loint(v)), hi = hand1<S>((unsigned)__double2hiint(v));
     return __hiloint2double((int)hi, (int)lo);
 }
 
@@ -115,7 +145,7 @@ __device__ __forceinline__ double from_below(double v)
 template <typename T, int S, int PL, int D>
 __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL], const T (&hi)[PL], T &hand_r, T &hand_i,
                                           __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ry, unsigned &so, unsigned xstep,
-                                          unsigned xwrap, unsigned kv, bool stage0, int tau0, int t_lo, int t_hi,
+                                          unsigned xwrap, unsigned kv, unsigned kvs, int tau0, int t_lo,
                                           bool store_lane, int rem, const MacArgs &a)
 {
     constexpr int G = PL + D;
@@ -127,9 +157,8 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
 #endif
 #if !(BFIR_SYS_EXP & 2)
         {   // stage j's x[newest - PL] -> stage j + 1's newest of the next slot; stage 0 keeps what it loaded
-            const T dx = from_below(W[(u + D) % G].x), dy = from_below(W[(u + D) % G].y);
-            W[(u + 1) % G].x = stage0 ? W[(u + 1) % G].x : dx;
-            W[(u + 1) % G].y = stage0 ? W[(u + 1) % G].y : dy;
+            W[(u + 1) % G].x = relay_t<S>(W[(u + 1) % G].x, W[(u + D) % G].x);
+            W[(u + 1) % G].y = relay_t<S>(W[(u + 1) % G].y, W[(u + D) % G].y);
         }
 #endif
 #if !(BFIR_SYS_EXP & 8)
@@ -155,18 +184,17 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
         // the top stage holds the finished y[tau - (S - 1)]
         const int ty = tau0 + u - (S - 1);
 #if !(BFIR_SYS_EXP & 4)
-        if (ty >= t_lo && ty < t_hi && store_lane) {
+        // the lanes below the top stage (and bin 0) carry a byte offset beyond the end of every product-spectra buffer
+        // (kvs): the buffer range check drops their stores -- cheaper than an exec-mask round trip per slot
+        if (ty >= t_lo) {                                        // scalar; ty < t_hi by the slot count of the run
             Cx<T> v; v.x = ar; v.y = ai;
-            sys_store<T, (BFIR_NT_Y & 1) ? 2 : 0>(ry, kv, (unsigned)BFIR_YSLOT(a, ty) * xstep, v);
+            sys_store<T, (BFIR_NT_Y & 1) ? 2 : 0>(ry, kvs, (unsigned)BFIR_YSLOT(a, ty) * xstep, v);
         }
 #else
         if (ty == -12345 && store_lane) { Cx<T> v; v.x = ar; v.y = ai; sys_store<T, 0>(ry, kv, 0, v); }
 #endif
 #if !(BFIR_SYS_EXP & 1)
-        {
-            const T br = from_below(ar), bi = from_below(ai);
-            hand_r = stage0 ? (T)0 : br; hand_i = stage0 ? (T)0 : bi;
-        }
+        hand_r = hand_t<S>(ar); hand_i = hand_t<S>(ai);
 #else
         hand_r = ar; hand_i = ai;
 #endif
@@ -228,9 +256,8 @@ __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(Ma
     const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
     const int s = w / nR, r = w - s * nR;
     const int gc = s / ncol, col = s - gc * ncol;
-    const int stage = threadIdx.x & (S - 1);
-    const bool stage0 = stage == 0;
-    const unsigned k = col * BPW + threadIdx.x / S;             // bin
+    const int stage = SysLanes<S>::stage(threadIdx.x);
+    const unsigned k = col * BPW + SysLanes<S>::bin(threadIdx.x);   // bin
     // byte offset of the bin's real part inside a spectrum (its imaginary part: + 4 in pairs, + 32 in groups of four)
     const unsigned kv = F32 ? k * 8u : ((k >> 2) * 8u + (k & 3u)) * 8u;
     const T *__restrict__ Hc = (const T *)a.h + (long)gc * a.h_ch_stride;
@@ -269,9 +296,10 @@ __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(Ma
     unsigned so = __builtin_amdgcn_readfirstlane(slot_of(t_lo + D) * xstep);   // stage 0's time from here on: wave-uniform
     T hand_r = 0, hand_i = 0;
     const bool store_lane = stage == S - 1 && k != 0;          // bin 0 belongs to the DC / Nyquist workgroups
+    const unsigned kvs = store_lane ? kv : 0x80000000u;        // out of range: mac_sys_supported keeps the buffers below 2 GiB
     int left = t_hi - t_lo + (S - 1);                           // slots: the last output leaves the top stage S - 1 slots later
     for (int tau = t_lo; left > 0; tau += G, left -= G)
-        sys_group<T, S, PL, D>(W, hr, hi, hand_r, hand_i, rx, ry, so, xstep, xwrap, kv, stage0, tau, t_lo, t_hi, store_lane, left, a);
+        sys_group<T, S, PL, D>(W, hr, hi, hand_r, hand_i, rx, ry, so, xstep, xwrap, kv, kvs, tau, t_lo, store_lane, left, a);
 }
 
 }  // namespace
@@ -305,6 +333,9 @@ template <typename T, int S, int PL, int D> static void launch_sys(const MacArgs
 bool mac_sys_supported(const MacArgs &a)
 {
     if (a.N < 512) return false;
+    // 32-bit byte offsets into one channel's delay line, and 2 GiB as the "nowhere" offset of the lanes that do not store
+    const unsigned long long spec = (unsigned long long)a.N * (unsigned)a.realsize;
+    if (spec * (unsigned)a.ring >= (1ull << 32) || spec * (unsigned)a.n_t > (1ull << 31)) return false;
     if (a.realsize == 4) return a.interleaved && a.B <= 128;
     return !a.interleaved && a.B <= 64;
 }

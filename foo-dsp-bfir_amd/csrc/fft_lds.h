@@ -47,6 +47,10 @@ static __device__ unsigned long long g_trace[3][BFIR_TRACE_WGS * BFIR_TRACE_SLOT
 #define BFIR_STAMP(kern, n) do { } while (0)
 #endif
 
+#ifndef BFIR_F64_EARLY_TW
+#define BFIR_F64_EARLY_TW(lg) ((lg) >= 12)
+#endif
+
 namespace bfir {
 
 // Force the values to exist in registers at this point of the program.  LLVM's sinking passes
@@ -317,13 +321,15 @@ template <typename T, int LOG2M, int SIGN> struct LdsFft {
         }
     }
 
-    // one pass after the first: twiddle fetch, exchange, butterflies.  fp64 transforms have no
-    // registers to spare for the early fetch (data alone is 2 x 2P registers), they load late.
+    // one pass after the first: twiddle fetch, exchange, butterflies.  Small fp64 transforms have no
+    // registers to spare for the early fetch (data alone is 2 x 2P registers; their occupancy is bound by
+    // registers), they load late; from 4096 points on the LDS buffer (66 KB) allows two workgroups per CU
+    // whatever the register count, and the fetch goes in front of the exchange as in fp32.
     template <int S>
     __device__ __forceinline__ static void pass(T *re, T *im, V2 *lds, const V2 *__restrict__ tw, int tid)
     {
         V2 w[ntw<S>()];
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4 || BFIR_F64_EARLY_TW(LOG2M)) {
             load_twiddles<S>(w, tw, tid);
             exchange<S - 1>(re, im, lds, tid);
         } else {

@@ -15,7 +15,9 @@
 // reference cbuf.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fft_lds.h"
@@ -149,23 +151,23 @@ bool direct_stereo_supported(int filter_length, int realsize)
     }
     return ok;
 }
-// float frames of an engine with an even channel count: a workgroup takes the two channels of a PAIR.  Stereo frames
-// are moved two at a time (16 bytes per lane: blocks on 16-byte boundaries), wider frames 8 bytes (one pair of one
-// frame) per lane.
-static bool direct_stereo_ok(int raw_bytes, int C, const void *raw, long eng_stride_samples, long frame_off)
+// float (or, for fp64 engines, double) frames of an engine with an even channel count: a workgroup takes the two channels
+// of a PAIR.  Stereo frames are moved two at a time (four samples per lane: blocks on four-sample boundaries), wider frames
+// two samples (one pair of one frame) per lane.
+static bool direct_stereo_ok(int raw_bytes, int realsize, int C, const void *raw, long eng_stride_samples, long frame_off)
 {
-    if (raw_bytes != 4 || C < 2 || (C & 1)) return false;
-    if (C == 2) return ((uintptr_t)raw % 16) == 0 && (eng_stride_samples % 4) == 0 && (frame_off % 2) == 0;
-    return ((uintptr_t)raw % 8) == 0 && (eng_stride_samples % 2) == 0;
+    if ((raw_bytes != 4 && !(raw_bytes == 8 && realsize == 8)) || C < 2 || (C & 1)) return false;
+    if (C == 2) return ((uintptr_t)raw % (4 * raw_bytes)) == 0 && (eng_stride_samples % 4) == 0 && (frame_off % 2) == 0;
+    return ((uintptr_t)raw % (2 * raw_bytes)) == 0 && (eng_stride_samples % 2) == 0;
 }
 
 // ---------------------------------------------------------------------------
 // a6 + a7: forward real FFT into the grouped layout
 // ---------------------------------------------------------------------------
 // TR: type of the raw samples in direct mode (FwdArgs.raw_bytes), void for the planar source.
-// CPW = 2 (direct mode, float frames of stereo engines): one workgroup of 2 NT threads transforms BOTH channels
-// of a block, each half in its own LDS buffer, so that the interleaved frames are moved 16 bytes per lane (two
-// whole frames) instead of 4 bytes at a stride.
+// CPW = 2 (direct mode, float frames -- or double frames of an fp64 engine -- with an even channel count): one workgroup of
+// 2 NT threads transforms BOTH channels of a pair, each half in its own LDS buffer, so that the interleaved frames are
+// moved four samples per lane (two whole stereo frames) instead of one sample at a stride.
 template <typename T, int LOG2M, bool ILV, typename TR = void, int CPW = 1>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
                                                                  const typename Vec2<T>::type *__restrict__ tw,
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
     __shared__ __attribute__((aligned(16))) V2 lds_all[CPW][F::LDS_ELEMS];
 
     constexpr bool DIRECT = !std::is_void<TR>::value;
-    static_assert(CPW == 1 || (CPW == 2 && DIRECT && std::is_same<TR, float>::value), "two channels per workgroup: stereo float frames");
+    static_assert(CPW == 1 || (CPW == 2 && DIRECT && (std::is_same<TR, float>::value || std::is_same<TR, T>::value)), "two channels per workgroup: float frames, or frames of the engine's own type");
     const int half = CPW == 1 ? 0 : (int)threadIdx.x / NT;         // which channel of the frame (wave-uniform: NT >= 64)
     const int tid = CPW == 1 ? (int)threadIdx.x : (int)threadIdx.x - half * NT;
     V2 *lds = lds_all[half];
@@ -200,53 +202,56 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
     T re[P], im[P];
     const T ls = (T)a.load_scale;
     if constexpr (DIRECT && CPW == 2) {
+      using RS = typename std::conditional<DIRECT, TR, float>::type;
+      using R2 = typename Vec2<RS>::type;
+      using R4 = typename Vec4<RS>::type;
       if (a.C == 2) {
-        // stereo float frames: float4 m of a block = frames 2m, 2m+1 = (l, r, l, r); 16-byte aligned (launcher)
+        // stereo frames: quad m of a block = frames 2m, 2m+1 = (l, r, l, r); aligned to four samples (launcher)
         const int g = gc >> 1;
         const long ho = (long)g * a.hist_eng_stride;
-        const float4 *__restrict__ rc4 = (const float4 *)((const float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
-        const float4 *__restrict__ ro4 = (t == 0) ? (const float4 *)((const float *)a.prev_raw + ho) : rc4 - M / 2;
+        const R4 *__restrict__ rc4 = (const R4 *)((const RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
+        const R4 *__restrict__ ro4 = (t == 0) ? (const R4 *)((const RS *)a.prev_raw + ho) : rc4 - M / 2;
 #pragma unroll
         for (int e = 0; e < P; e++) {
             const int m = F::in_index(tid, e);
             if (m < M / 2) {                                   // frames 2m, 2m+1 of the previous block
-                const float4 v = ro4[m];
+                const R4 v = ro4[m];
                 re[e] = (T)(half ? v.y : v.x) * ls; im[e] = (T)(half ? v.w : v.z) * ls;
                 if (a.n_t == 1 && half == 0)                   // one-block chunk: the other history block moves on unchanged
-                    ((float4 *)((float *)a.save_prev + ho))[m] = ((const float4 *)((const float *)a.carry + ho))[m];
+                    ((R4 *)((RS *)a.save_prev + ho))[m] = ((const R4 *)((const RS *)a.carry + ho))[m];
             } else {                                           // frames of this block
-                const float4 v = rc4[m - M / 2];
+                const R4 v = rc4[m - M / 2];
                 re[e] = (T)(half ? v.y : v.x) * ls; im[e] = (T)(half ? v.w : v.z) * ls;
                 // the engine's history: raw frames of the last two blocks of the chunk (whole frames: one half stores)
                 if (t >= a.n_t - 2 && half == 0)
-                    ((float4 *)((float *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho))[m - M / 2] = v;
+                    ((R4 *)((RS *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho))[m - M / 2] = v;
             }
         }
       } else {
         // wider frames, even channel count (round 3): the workgroup's two channels are the pair (c0, c0 + 1) of every
-        // frame, 8 bytes per frame at the frame stride -- the access pattern of the fp32 pair kernels
+        // frame, two samples per frame at the frame stride -- the access pattern of the fp32 pair kernels
         const int C = a.C, g = gc / C, c0 = gc - g * C - half;
         const long ho = (long)g * a.hist_eng_stride + c0;
-        const float *__restrict__ rc = (const float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c0;
-        const float *__restrict__ ro = (t == 0) ? (const float *)a.prev_raw + ho : rc - (long)M * C;
+        const RS *__restrict__ rc = (const RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c0;
+        const RS *__restrict__ ro = (t == 0) ? (const RS *)a.prev_raw + ho : rc - (long)M * C;
 #pragma unroll
         for (int e = 0; e < P; e++) {
             const int m = F::in_index(tid, e);
             if (m < M / 2) {                                   // frames 2m, 2m+1 of the previous block
-                const float2 v0 = *(const float2 *)(ro + (long)(2 * m) * C), v1 = *(const float2 *)(ro + (long)(2 * m + 1) * C);
+                const R2 v0 = *(const R2 *)(ro + (long)(2 * m) * C), v1 = *(const R2 *)(ro + (long)(2 * m + 1) * C);
                 re[e] = (T)(half ? v0.y : v0.x) * ls; im[e] = (T)(half ? v1.y : v1.x) * ls;
                 if (a.n_t == 1 && half == 0) {                 // one-block chunk: the other history block moves on unchanged
-                    float *sp = (float *)a.save_prev + ho; const float *cr = (const float *)a.carry + ho;
-                    *(float2 *)(sp + (long)(2 * m) * C) = *(const float2 *)(cr + (long)(2 * m) * C);
-                    *(float2 *)(sp + (long)(2 * m + 1) * C) = *(const float2 *)(cr + (long)(2 * m + 1) * C);
+                    RS *sp = (RS *)a.save_prev + ho; const RS *cr = (const RS *)a.carry + ho;
+                    *(R2 *)(sp + (long)(2 * m) * C) = *(const R2 *)(cr + (long)(2 * m) * C);
+                    *(R2 *)(sp + (long)(2 * m + 1) * C) = *(const R2 *)(cr + (long)(2 * m + 1) * C);
                 }
             } else {                                           // frames of this block
                 const int n = 2 * m - M;
-                const float2 v0 = *(const float2 *)(rc + (long)n * C), v1 = *(const float2 *)(rc + (long)(n + 1) * C);
+                const R2 v0 = *(const R2 *)(rc + (long)n * C), v1 = *(const R2 *)(rc + (long)(n + 1) * C);
                 re[e] = (T)(half ? v0.y : v0.x) * ls; im[e] = (T)(half ? v1.y : v1.x) * ls;
                 if (t >= a.n_t - 2 && half == 0) {             // the engine's history (one half stores the pair)
-                    float *kp = (float *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho;
-                    *(float2 *)(kp + (long)n * C) = v0; *(float2 *)(kp + (long)(n + 1) * C) = v1;
+                    RS *kp = (RS *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho;
+                    *(R2 *)(kp + (long)n * C) = v0; *(R2 *)(kp + (long)(n + 1) * C) = v1;
                 }
             }
         }
@@ -344,6 +349,237 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_fwd(FwdArgs a,
     BFIR_STAMP(0, 10);
 }
 
+// ---------------------------------------------------------------------------
+// k_fwd_run: the forward kernel of fp64 engines in direct mode, one channel per workgroup, as a RUN of blocks
+// ---------------------------------------------------------------------------
+// A 4096-point double transform holds 66 KB of LDS: two workgroups of four waves per CU, and nothing hides the latency of
+// the frame loads in front of every transform (scripts/trace_phases_f64.py: 6.6 of a workgroup's 22.7 us in cfg5, the
+// frames being 8 bytes at a 16-byte stride).  Here a workgroup walks run_len consecutive blocks of ONE channel:
+//   * the window's first half is the block it transformed last -- kept in registers, never loaded again;
+//   * block t + 1 is fetched under the split and the stores of block t.  Vector-memory operations return in order, so a
+//     twiddle load issued behind that fetch would wait for it: the twiddles come from a handful of BASES instead, loaded once per
+//     workgroup (the last pass's six in registers, the earlier passes' in 1.5 KB of LDS) and multiplied up as needed --
+//     the persistent fp32 kernels' scheme (pair.hip, fft_lds.h butterflies_tb).  A derived twiddle is the rounded product
+//     of two rounded roots of unity, so the spectra differ from k_fwd's in the last bit or two (1e-16 relative): every
+//     launch of such an engine, whatever its size, goes through this kernel, so results do not depend on the chunking.
+// Addressing: buffer descriptors (wave-uniform base, 32-bit lane offset, scalar offset per access) -- sixteen 64-bit
+// addresses per stream would cost the registers that keep two workgroups on a CU.
+typedef unsigned int run_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int run_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t run_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long u = (unsigned long long)p;     // workgroup-uniform by construction
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void run_load(float &v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void run_load(double &v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const run_u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    v = __hiloint2double((int)q.y, (int)q.x);
+}
+__device__ __forceinline__ void run_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void run_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    run_u32x2 q; q.x = (unsigned)__double2loint(v); q.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
+}
+__device__ __forceinline__ double2 run_load_v2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const run_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    double2 v; v.x = __hiloint2double((int)q.y, (int)q.x); v.y = __hiloint2double((int)q.w, (int)q.z);
+    return v;
+}
+__device__ __forceinline__ void run_store_v2(double2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    run_u32x4 q;
+    q.x = (unsigned)__double2loint(v.x); q.y = (unsigned)__double2hiint(v.x);
+    q.z = (unsigned)__double2loint(v.y); q.w = (unsigned)__double2hiint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, 0);
+}
+
+// exp(-2 pi i j / 32), j < 16 (forward convention): the rotation between the split twiddles of a thread's points, which lie
+// M / 16 bins apart (W_N^(k0 + j M / 16) = W_N^k0 exp(-2 pi i j / 32), N = 2 M).  The seven constants come from constant
+// memory through SCALAR loads: as literals the compiler keeps them in fourteen vector registers across the transform loop,
+// which k_fwd_run<12, double> does not have (it spilled, and a scratch reload waits behind the prefetch like any other
+// vector-memory load).
+__constant__ double k_w32_cos[8] = {1.0, 0.9807852804032304491262, 0.9238795325112867561282, 0.8314696123025452370788,
+                                    0.7071067811865475244008, 0.5555702330196022247428, 0.3826834323650897717285,
+                                    0.1950903220161282678483};
+template <int J> __device__ __forceinline__ void mul_w32(double &re, double &im)
+{
+    static_assert(J >= 0 && J < 16, "a 32nd root of unity, lower half plane");
+    if constexpr (J == 0) {
+    } else if constexpr (J == 8) {               // -i
+        const double t = re; re = im; im = -t;
+    } else {
+        // cos(2 pi J / 32), sin(2 pi J / 32) from the first-octant table: cos(x) = sin(pi / 2 - x), cos(pi - x) = -cos(x)
+        constexpr int jc = J < 8 ? J : 16 - J, js = J < 8 ? 8 - J : J - 8;
+        const double c = J < 8 ? k_w32_cos[jc] : -k_w32_cos[jc], sn = k_w32_cos[js];
+        const double tr = re * c + im * sn, ti = im * c - re * sn;
+        re = tr; im = ti;
+    }
+}
+
+template <int LOG2M, typename TR>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_fwd_run(FwdArgs a, const double2 *__restrict__ twb,
+                                                                  const double2 *__restrict__ ws, int run_len)
+{
+    using T = double;
+    using F = LdsFft<T, LOG2M, -1>;
+    using V2 = double2;
+    constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M, H = P / 2;
+    static_assert(F::radix(0) == P, "in_index(tid, e) = tid + e NT: slots e < P / 2 are the window's first half");
+    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) V2 ldsb[F::LDSB_ELEMS];
+    const int tid = threadIdx.x;
+    // (run, channel): the channels of a run share input cache lines -> neighbours on one XCD
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int r = wi / a.n_ch, gc = wi - r * a.n_ch;
+    const int t0 = r * run_len, t1 = min(a.n_t, t0 + run_len);
+    if (t0 >= t1) return;
+    const int C = a.C, g = gc / C, c = gc - g * C;
+    const long ho = (long)g * a.hist_eng_stride + c;
+    const TR *__restrict__ raw = (const TR *)a.raw + (long)g * a.raw_eng_stride + a.frame_off * C + c;   // frame 0 of block 0
+    const T ls = (T)a.load_scale, os = (T)a.out_scale;
+    // frames 2 (tid + e NT), + 1 of a block: byte offsets of the lane, between a thread's points, between the two frames
+    const unsigned blk_bytes = (unsigned)M * C * (unsigned)sizeof(TR);
+    const unsigned fo = (unsigned)(2 * tid) * C * (unsigned)sizeof(TR), estep = (unsigned)(2 * NT) * C * (unsigned)sizeof(TR);
+    const unsigned fstep = (unsigned)C * (unsigned)sizeof(TR);
+    const V2 wb = ws[tid];                                     // W_N^tid; the other fifteen split twiddles of a thread: mul_w32
+
+    V2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);                          // the first exchange's barrier publishes ldsb
+    T oldr[H], oldi[H];
+    TR nx0[H], nx1[H];
+    {
+        const __amdgpu_buffer_rsrc_t ro = run_rsrc((t0 == 0) ? (const TR *)a.prev_raw + ho : raw + (long)(t0 - 1) * M * C, blk_bytes);
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            TR x0, x1;
+            run_load(x0, ro, fo, e * estep); run_load(x1, ro, fo, e * estep + fstep);
+            oldr[e] = (T)x0 * ls; oldi[e] = (T)x1 * ls;
+        }
+        if (a.n_t == 1) {                                      // one-block chunk: the other history block moves on unchanged
+            const __amdgpu_buffer_rsrc_t rcr = run_rsrc((const TR *)a.carry + ho, blk_bytes), rsp = run_rsrc((TR *)a.save_prev + ho, blk_bytes);
+#pragma unroll
+            for (int e = 0; e < H; e++) {
+                TR x0, x1;
+                run_load(x0, rcr, fo, e * estep); run_load(x1, rcr, fo, e * estep + fstep);
+                run_store(x0, rsp, fo, e * estep); run_store(x1, rsp, fo, e * estep + fstep);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rc = run_rsrc(raw + (long)t0 * M * C, blk_bytes);
+#pragma unroll
+        for (int e = 0; e < H; e++) { run_load(nx0[e], rc, fo, e * estep); run_load(nx1[e], rc, fo, e * estep + fstep); }
+    }
+    T *__restrict__ dch = (T *)a.dst + (long)gc * a.dst_ch_stride;
+    for (int t = t0; t < t1; t++) {
+        T re[P], im[P];
+        if (t >= a.n_t - 2) {                                  // the engine's history: raw frames of the chunk's last two blocks
+            const __amdgpu_buffer_rsrc_t rk = run_rsrc((TR *)(t == a.n_t - 1 ? a.save_last : a.save_prev) + ho, blk_bytes);
+#pragma unroll
+            for (int e = 0; e < H; e++) { run_store(nx0[e], rk, fo, e * estep); run_store(nx1[e], rk, fo, e * estep + fstep); }
+        }
+#pragma unroll
+        for (int e = 0; e < H; e++) {                          // window = [block t-1 | block t]
+            re[e] = oldr[e]; im[e] = oldi[e];
+            oldr[e] = (T)nx0[e] * ls; oldi[e] = (T)nx1[e] * ls;
+            re[H + e] = oldr[e]; im[H + e] = oldi[e];
+        }
+        {
+            V2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            // LDS addresses are formed afresh per phase from an opaque copy of the lane index: otherwise the compiler
+            // hoists dozens of them out of the transform loop (and the registers are spoken for)
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+        });
+        {
+            // block t + 1 under the split and the stores of block t (behind the butterflies: their registers are free now);
+            // past the end of the run a zero-byte descriptor (zeros, no branch)
+            const __amdgpu_buffer_rsrc_t rn_ = run_rsrc(raw + (long)(t + 1) * M * C, t + 1 < t1 ? blk_bytes : 0u);
+#pragma unroll
+            for (int e = 0; e < H; e++) { run_load(nx0[e], rn_, fo, e * estep); run_load(nx1[e], rn_, fo, e * estep + fstep); }
+        }
+        // Z in natural order to LDS so every thread can fetch Z[M-k]; from here on k_fwd's own steps
+        int tz = tid; asm volatile("" : "+v"(tz));
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            V2 v; v.x = re[e]; v.y = im[e];
+            lds[F::phys(F::out_index(tz, e))] = v;
+        }
+        __syncthreads();
+        // an opaque copy per transform: left alone the compiler forms all fifteen rotated twiddles once, in front of the loop,
+        // and carries 60 registers through it
+        T wbx = wb.x, wby = wb.y; asm volatile("" : "+v"(wbx), "+v"(wby));
+        static_for<0, P>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            static_assert(F::out_index(0, e) % NT == 0 && F::out_index(0, e) / NT < 16, "a thread's bins lie M / 16 apart");
+            const int k = F::out_index(tz, e);
+            V2 pz = lds[F::phys((M - k) & (M - 1))];
+            T wx = wbx, wy = wby;
+            mul_w32<F::out_index(0, e) / NT>(wx, wy);
+            T er = (T)0.5 * (re[e] + pz.x), ei = (T)0.5 * (im[e] - pz.y);
+            T orr = (T)0.5 * (im[e] + pz.y), oi = (T)-0.5 * (re[e] - pz.x);
+            T tr = orr * wx - oi * wy, ti = orr * wy + oi * wx;
+            T xr = er + tr, xi = ei + ti;
+            if (k == 0) xi = re[e] - im[e];
+            re[e] = xr * os; im[e] = xi * os;
+        });
+        pin_registers(re, im);
+        __syncthreads();
+        T *ldsr = (T *)lds;
+        int ty = tid; asm volatile("" : "+v"(ty));
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            const int k = F::out_index(ty, e);
+            ldsr[8 * (k >> 2) + (k & 3)] = re[e];
+            ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rd = run_rsrc(dch + (long)((a.base_slot + t) % a.ring) * N, (unsigned)N * 8u);
+#pragma unroll
+        for (int j = 0; j < P / 2; j++) {
+            const V2 *sp = (const V2 *)ldsr + 2 * (ty + j * NT);
+            run_store_v2(sp[0], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u);
+            run_store_v2(sp[1], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u + 16u);
+        }
+        // the next transform's first exchange starts with a barrier
+    }
+}
+
+// blocks per workgroup of k_fwd_run / k_inv_run: one round of the 512 resident workgroups (256 CUs x 2) where the launch
+// has that many blocks, never more than 8 (cfg5: 42.6 / 42.8 / 42.1 Gsamples/s at 4 / 8 / 16; short runs keep the three kernels of
+// the pipeline close together in time);
+// BFIR_RUN64 overrides (0 = the one-transform kernels)
+#ifndef BFIR_RUN64_MIN_LOG2M
+#define BFIR_RUN64_MIN_LOG2M 10
+#endif
+bool run64_supported(int filter_length, int realsize)
+{
+    if (const char *e = getenv("BFIR_RUN64")) if (atoi(e) == 0) return false;
+    return realsize == 8 && filter_length >= (1 << BFIR_RUN64_MIN_LOG2M) && filter_length <= 8192;
+}
+static int run64_len(int n_t, int n_ch)
+{
+    if (const char *e = getenv("BFIR_RUN64")) return atoi(e);
+    const int runs = std::max(1, 512 / std::max(1, n_ch));
+    return std::min(std::max(1, (n_t + runs - 1) / runs), 8);
+}
+
 template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, const FwdArgs &a, int items, hipStream_t s)
 {
     using V2 = typename Vec2<T>::type;
@@ -352,10 +588,31 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
     {
         if (a.raw_bytes) {           // direct mode: raw float / double frames in
             const bool il = sizeof(T) == 4 && a.interleaved;
+            // fp64, 1024 ... 8192 points: runs of blocks per workgroup, one channel each -- also where two channels per
+            // workgroup would fit: with the loads hidden the forward kernel is faster alone (0.35 against 0.43 ms per 32768
+            // blocks of the plug-in's shape) and in the pipeline (41.9 against 40.7 Gsamples/s at 8 channels); the INVERSE keeps
+            // the channel pairs where it can, whole output frames beating stores at a stride (profiles/r03_fp64.txt)
+            if constexpr (sizeof(T) == 8 && LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= 13) {
+                const int len = plan.twb ? run64_len(a.n_t, a.n_ch) : 0;
+                if (len > 0) {
+                    const int runs = (a.n_t + len - 1) / len;
+                    if (a.raw_bytes == 4)
+                        hipLaunchKernelGGL((k_fwd_run<LOG2M, float>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
+                    else
+                        hipLaunchKernelGGL((k_fwd_run<LOG2M, double>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
+                    return;
+                }
+            }
             if constexpr (direct_stereo_fits<T, LOG2M>()) {
-                if (direct_stereo_ok(a.raw_bytes, a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
-                    hipLaunchKernelGGL((k_fwd<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
-                                       (const V2 *)plan.tw, (const V2 *)plan.ws);
+                if (direct_stereo_ok(a.raw_bytes, (int)sizeof(T), a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
+                    if (a.raw_bytes == 4)
+                        hipLaunchKernelGGL((k_fwd<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+                    else
+                        hipLaunchKernelGGL((k_fwd<T, LOG2M, false, T, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
                     return;
                 }
             }
@@ -397,8 +654,8 @@ void launch_fwd(const FftPlan &plan, const FwdArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // a11 + a12: inverse real FFT from the grouped layout, valid half only
 // ---------------------------------------------------------------------------
-// CPW = 2: both channels of a stereo float-frame block in one workgroup (see k_fwd); the two valid halves meet
-// in LDS as whole frames and leave 16 bytes per lane.
+// CPW = 2: both channels of a pair in one workgroup (see k_fwd); the two valid halves meet in LDS as whole frames and
+// leave four samples (stereo) or two (wider frames) per lane.
 template <typename T, int LOG2M, bool ILV, typename TR = void, int CPW = 1>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
                                                                  const typename Vec2<T>::type *__restrict__ tw,
@@ -411,7 +668,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
     __shared__ __attribute__((aligned(16))) V2 lds_all[CPW][F::LDS_ELEMS];
 
     constexpr bool DIRECT = !std::is_void<TR>::value;
-    static_assert(CPW == 1 || (CPW == 2 && DIRECT && std::is_same<TR, float>::value), "two channels per workgroup: stereo float frames");
+    static_assert(CPW == 1 || (CPW == 2 && DIRECT && (std::is_same<TR, float>::value || std::is_same<TR, T>::value)), "two channels per workgroup: float frames, or frames of the engine's own type");
     const int half = CPW == 1 ? 0 : (int)threadIdx.x / NT;
     const int tid = CPW == 1 ? (int)threadIdx.x : (int)threadIdx.x - half * NT;
     V2 *lds = lds_all[half];
@@ -472,9 +729,11 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
         unsigned int *red_cnt = red_cnt_all[half];
         const int C = a.C, g = gc / C, c = gc - g * C;
         RS *__restrict__ out = (RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + c;
-        // CPW = 2: the frames are assembled in the first LDS buffer (2 M floats <= its size), which the other
+        // CPW = 2: the frames are assembled in the first LDS buffer (2 M raw samples <= its size), which the other
         // half's waves may still be reading for their last pass
-        float *stg = (float *)lds_all[0];
+        using R2 = typename Vec2<RS>::type;
+        using R4 = typename Vec4<RS>::type;
+        RS *stg = (RS *)lds_all[0];
         if constexpr (CPW == 2) __syncthreads();
         const T rmax = (T)a.max, rmin = (T)(-a.max);
         Bits mx = 0; unsigned int cnt = 0u;
@@ -483,7 +742,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
             const int m = F::out_index(tid, e);
             if (m < M / 2) {
                 const T v0 = re[e], v1 = im[e];
-                if constexpr (CPW == 2) { stg[4 * m + half] = (float)v0; stg[4 * m + 2 + half] = (float)v1; }   // frames 2m, 2m+1: (l, r, l, r)
+                if constexpr (CPW == 2) { stg[4 * m + half] = (RS)v0; stg[4 * m + 2 + half] = (RS)v1; }   // frames 2m, 2m+1: (l, r, l, r)
                 else { out[(long)(2 * m) * C] = (RS)v0; out[(long)(2 * m + 1) * C] = (RS)v1; }
                 // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
                 cnt += ((v0 < (T)0) ? (v0 < rmin) : (v0 > rmax)) ? 1u : 0u;
@@ -503,21 +762,21 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
         if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_cnt[tid >> 6] = cnt; }
         __syncthreads();
         if constexpr (CPW == 2) {
-            if (C == 2) {                                      // whole frames out: 2 M floats, 16 bytes per lane
-                float4 *__restrict__ out4 = (float4 *)((float *)a.raw + (long)(gc >> 1) * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
-                const float4 *stg4 = (const float4 *)stg;
+            if (C == 2) {                                      // whole frames out: 2 M samples, four per lane
+                R4 *__restrict__ out4 = (R4 *)((RS *)a.raw + (long)(gc >> 1) * a.raw_eng_stride + (a.frame_off + (long)t * M) * 2);
+                const R4 *stg4 = (const R4 *)stg;
 #pragma unroll
                 for (int j = 0; j < P / 4; j++) {
                     const int idx = (int)threadIdx.x + j * 2 * NT;
                     out4[idx] = stg4[idx];
                 }
-            } else {                                           // the pair's two floats of every frame, at the frame stride
-                float *__restrict__ outp = (float *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + (c - half);
-                const float2 *stg2 = (const float2 *)stg;
+            } else {                                           // the pair's two samples of every frame, at the frame stride
+                RS *__restrict__ outp = (RS *)a.raw + (long)g * a.raw_eng_stride + (a.frame_off + (long)t * M) * C + (c - half);
+                const R2 *stg2 = (const R2 *)stg;
 #pragma unroll
                 for (int j = 0; j < P / 2; j++) {
                     const int f = (int)threadIdx.x + j * 2 * NT;   // frame 0 .. M-1
-                    *(float2 *)(outp + (long)f * C) = stg2[f];
+                    *(R2 *)(outp + (long)f * C) = stg2[f];
                 }
             }
         }
@@ -541,6 +800,137 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
     BFIR_STAMP(1, 10);
 }
 
+// ---------------------------------------------------------------------------
+// k_inv_run: the inverse kernel of fp64 engines in direct mode, one channel per workgroup, as a RUN of blocks
+// ---------------------------------------------------------------------------
+// k_fwd_run's counterpart: the product spectrum of block t + 1 (N doubles: 32 bytes x P / 2 per lane) is fetched into
+// registers under the output phase of block t -- behind the butterflies, whose registers are free by then -- twiddles from
+// bases, the split twiddles from one table entry per thread times constant 32nd roots.  Steps, bookkeeping (overflow
+// statistics, NaN verdict: real2raw.cpp:321-336, brutefir.cpp:316-321) and output addressing are k_inv's.
+template <int LOG2M, typename TR>
+__global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_inv_run(InvArgs a, const double2 *__restrict__ twb,
+                                                                  const double2 *__restrict__ ws, int run_len)
+{
+    using T = double;
+    using F = LdsFft<T, LOG2M, +1>;
+    using V2 = double2;
+    constexpr int M = F::M, NT = F::NT, P = F::P, N = 2 * M;
+    static_assert(F::radix(0) == P, "in_index(tid, e) = tid + e NT");
+    __shared__ __attribute__((aligned(16))) V2 lds[F::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) V2 ldsb[F::LDSB_ELEMS];
+    using Bits = unsigned long long;
+    __shared__ Bits red_max[NT / 64 > 0 ? NT / 64 : 1];
+    __shared__ unsigned int red_cnt[NT / 64 > 0 ? NT / 64 : 1];
+    const int tid = threadIdx.x;
+    const int W = gridDim.x, b = blockIdx.x, xcd = b & 7, qn = W >> 3, rn = W & 7;
+    const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+    const int r = wi / a.n_ch, gc = wi - r * a.n_ch;
+    const int t0 = r * run_len, t1 = min(a.n_t, t0 + run_len);
+    if (t0 >= t1) return;
+    const int C = a.C, g = gc / C, c = gc - g * C;
+    const T *__restrict__ sch = (const T *)a.src + (long)gc * a.src_ch_stride;
+    TR *__restrict__ raw = (TR *)a.raw + (long)g * a.raw_eng_stride + a.frame_off * C + c;   // frame 0 of block 0
+    const unsigned blk_bytes = (unsigned)M * C * (unsigned)sizeof(TR);
+    const unsigned fo = (unsigned)(2 * tid) * C * (unsigned)sizeof(TR), fstep = (unsigned)C * (unsigned)sizeof(TR);
+    const T sc = (T)a.in_scale, rmax = (T)a.max, rmin = (T)(-a.max);
+    const V2 wb = ws[tid];
+    V2 B[F::NBREG];
+    F::load_bases(B, ldsb, twb, tid);
+
+    V2 nx[P];                                                  // the next block's spectrum as it lies in memory: quad tid + j NT
+    {
+        const __amdgpu_buffer_rsrc_t rs = run_rsrc(sch + (long)t0 * N, (unsigned)N * 8u);
+#pragma unroll
+        for (int j = 0; j < P / 2; j++) {
+            nx[2 * j] = run_load_v2(rs, (unsigned)tid * 32u, (unsigned)(j * NT) * 32u);
+            nx[2 * j + 1] = run_load_v2(rs, (unsigned)tid * 32u, (unsigned)(j * NT) * 32u + 16u);
+        }
+    }
+    for (int t = t0; t < t1; t++) {
+        // the spectrum to LDS (the last reads of this buffer lie in front of the barrier that closes the loop body)
+        T *ldsr = (T *)lds;
+        int tl0 = tid; asm volatile("" : "+v"(tl0));
+#pragma unroll
+        for (int j = 0; j < P / 2; j++) {
+            ((V2 *)ldsr)[2 * (tl0 + j * NT)] = nx[2 * j];
+            ((V2 *)ldsr)[2 * (tl0 + j * NT) + 1] = nx[2 * j + 1];
+        }
+        __syncthreads();
+        // Z_k = (X_k + conj X_{M-k}) + i conj(W^k) (X_k - conj X_{M-k})
+        T re[P], im[P];
+        T wbx = wb.x, wby = wb.y; asm volatile("" : "+v"(wbx), "+v"(wby));
+        static_for<0, P>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            static_assert(F::in_index(0, e) == e * NT, "a thread's bins lie M / 16 apart");
+            const int k = tl0 + e * NT;
+            const int q = (k == 0) ? 0 : M - k;
+            T xr = ldsr[8 * (k >> 2) + (k & 3)] * sc, xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
+            T yr = ldsr[8 * (q >> 2) + (q & 3)] * sc, yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+            if (k == 0) { yr = xi; xi = (T)0; yi = (T)0; }      // X_0 = (DC, 0), X_M = (Nyquist, 0)
+            T wx = wbx, wy = wby;
+            mul_w32<e>(wx, wy);
+            T ar = xr + yr, ai = xi - yi, br = xr - yr, bi = xi + yi;
+            T tr = br * wx + bi * wy, ti = bi * wx - br * wy;
+            re[e] = ar - ti; im[e] = ai + tr;
+        });
+        pin_registers(re, im);   // every read of the staged spectrum happens before the first exchange's barrier
+        {
+            // block t + 1's spectrum under the transform and the output of block t (the output phase alone is too short); past the end of the run a zero-byte descriptor
+            const __amdgpu_buffer_rsrc_t rs = run_rsrc(sch + (long)(t + 1) * N, t + 1 < t1 ? (unsigned)N * 8u : 0u);
+#pragma unroll
+            for (int j = 0; j < P / 2; j++) {
+                nx[2 * j] = run_load_v2(rs, (unsigned)tid * 32u, (unsigned)(j * NT) * 32u);
+                nx[2 * j + 1] = run_load_v2(rs, (unsigned)tid * 32u, (unsigned)(j * NT) * 32u + 16u);
+            }
+        }
+        {
+            V2 w0[1];
+            F::template butterflies<0>(re, im, w0);
+        }
+        static_for<1, F::NP>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            int tl = tid; asm volatile("" : "+v"(tl));
+            F::template exchange<S - 1>(re, im, lds, tl);
+            F::template butterflies_tb<S>(re, im, B, ldsb, tl);
+        });
+        // valid half -> raw output frames of this channel, with real2raw's bookkeeping
+        const __amdgpu_buffer_rsrc_t ro = run_rsrc(raw + (long)t * M * C, blk_bytes);
+        Bits mx = 0; unsigned int cnt = 0u;
+        static_for<0, P>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            constexpr int m0 = F::out_index(0, e);
+            if constexpr (m0 < M / 2) {                         // point m = tid + m0: frames 2m, 2m+1
+                const T v0 = re[e], v1 = im[e];
+                run_store((TR)v0, ro, fo, (unsigned)(2 * m0) * fstep);
+                run_store((TR)v1, ro, fo, (unsigned)(2 * m0 + 1) * fstep);
+                // brutefir/real2raw.cpp:321-336: strict compares, NaN never counts
+                cnt += ((v0 < (T)0) ? (v0 < rmin) : (v0 > rmax)) ? 1u : 0u;
+                cnt += ((v1 < (T)0) ? (v1 < rmin) : (v1 > rmax)) ? 1u : 0u;
+                const Bits b0 = (v0 == v0) ? abs_bits(v0) : (Bits)0, b1 = (v1 == v1) ? abs_bits(v1) : (Bits)0;
+                mx = b0 > mx ? b0 : mx; mx = b1 > mx ? b1 : mx;
+                // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
+                if (m0 == 0 && tid == 0 && !isfinite(v0)) atomicMin(a.bad_block, a.block_base + t);
+            }
+        });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const Bits om = __shfl_xor(mx, o);
+            mx = om > mx ? om : mx;
+            cnt += __shfl_xor(cnt, o);
+        }
+        if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_cnt[tid >> 6] = cnt; }
+        __syncthreads();                                       // also: every wave is through with the transform's LDS buffer
+        if (tid == 0) {
+            Bits m2 = 0; unsigned int n2 = 0u;
+            for (int wv = 0; wv < (NT + 63) / 64; wv++) { m2 = red_max[wv] > m2 ? red_max[wv] : m2; n2 += red_cnt[wv]; }
+            DevOverflow *of = of_shard(a.overflow, a.of_shard_stride) + gc;
+            if (n2) atomicAdd(&of->n_overflows, n2);
+            // no look at the current maximum first (k_inv does): a load here would wait for the prefetch
+            if (m2) atomicMax(&of->largest_bits, (unsigned long long)m2);
+        }
+    }
+}
+
 template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, const InvArgs &a, int items, hipStream_t s)
 {
     using V2 = typename Vec2<T>::type;
@@ -550,9 +940,26 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
         if (a.raw_bytes) {           // direct mode: raw float / double frames out
             const bool il = sizeof(T) == 4 && a.interleaved;
             if constexpr (direct_stereo_fits<T, LOG2M>()) {
-                if (direct_stereo_ok(a.raw_bytes, a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
-                    hipLaunchKernelGGL((k_inv<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
-                                       (const V2 *)plan.tw, (const V2 *)plan.ws);
+                if (direct_stereo_ok(a.raw_bytes, (int)sizeof(T), a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
+                    if (a.raw_bytes == 4)
+                        hipLaunchKernelGGL((k_inv<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+                    else
+                        hipLaunchKernelGGL((k_inv<T, LOG2M, false, T, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+                    return;
+                }
+            }
+            if constexpr (sizeof(T) == 8 && LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= 13) {
+                const int len = plan.twb && !a.full_output ? run64_len(a.n_t, a.n_ch) : 0;
+                if (len > 0) {
+                    const int runs = (a.n_t + len - 1) / len;
+                    if (a.raw_bytes == 4)
+                        hipLaunchKernelGGL((k_inv_run<LOG2M, float>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
+                    else
+                        hipLaunchKernelGGL((k_inv_run<LOG2M, double>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
+                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
                     return;
                 }
             }

@@ -262,6 +262,26 @@ def test_create_rejects_bad_arguments(bfir):
         bfir.Brutefir(1024, 2, 4, 2, in_format=12)  # not a BF_SAMPLE_FORMAT_* code
 
 
+def _run_kernel_twiddles(s, L):
+    """fp64 engines with 1024 <= L <= 8192 in direct mode transform runs of blocks in k_fwd_run (and, one channel per
+    workgroup, k_inv_run; kernels.hip), whose twiddles are products of a few base roots instead of table entries: spectra
+    equal to the one-transform kernels' to a few 1e-16, not to the bit (chunking still never changes a bit: every launch of
+    such an engine goes through the same kernel)."""
+    return s == 8 and 1024 <= L <= 8192
+
+
+def _same_outputs(a, b, s, L, out_is_f32=False):
+    if not _run_kernel_twiddles(s, L):
+        return np.array_equal(a, b)
+    return rel_err(a, b) <= (2e-7 if out_is_f32 else 1e-14)
+
+
+def _same_stats(a, b, s, L):
+    if not _run_kernel_twiddles(s, L):
+        return a == b
+    return all(na == nb_ and abs(la - lb) <= 1e-6 * max(abs(lb), 1e-300) for (na, la), (nb_, lb) in zip(a, b))
+
+
 @pytest.mark.parametrize("s,L,B,C,in_fmt,out_fmt", [(8, 1024, 5, 2, 8, 8),     # the plug-in: REALSIZE 8, float32 frames
                                                    (8, 2048, 3, 2, 8, 8),     # ... both channels in one workgroup
                                                    (8, 256, 3, 3, 10, 10), (4, 256, 4, 3, 8, 8), (4, 16384, 2, 1, 8, 10),
@@ -269,8 +289,8 @@ def test_create_rejects_bad_arguments(bfir):
 def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, in_fmt, out_fmt):
     """Engines outside the float fast path whose frames are FLOAT_LE / FLOAT64_LE read and write the raw frames
     from inside k_fwd / k_inv (direct mode) instead of through k_stage_in / k_stage_out and planar buffers:
-    the same arithmetic, so the same bits -- across chunked launches, one-block calls, reset and the
-    overflow bookkeeping -- and within tolerance of the oracle."""
+    the same arithmetic, so the same bits (_run_kernel_twiddles: the one exception) -- across chunked launches,
+    one-block calls, reset and the overflow bookkeeping -- and within tolerance of the oracle."""
     import os
     nb = 13
     rng = np.random.default_rng(L + C)
@@ -289,7 +309,7 @@ def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, i
         stats += [(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(C)]
         outs.append((np.concatenate(parts), stats))
         eng.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert _same_outputs(outs[0][0], outs[1][0], s, L, out_fmt == 8) and _same_stats(outs[0][1], outs[1][1], s, L)
     assert all(big > 0.0 for _, big in outs[0][1][:C])          # the peak bookkeeping ran (counts depend on the data)
     ref = orc.Engine(L, B, s, C, in_fmt, out_fmt); ref.set_coeff(h, scale=12.0)
     y_ref = ref.run(x)[1]
@@ -298,9 +318,10 @@ def test_direct_path_equals_staging_kernels_bit_for_bit(orc, bfir, s, L, B, C, i
 
 @pytest.mark.parametrize("misalign", [0, 8])
 def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
-    """The plug-in's shape (REALSIZE 8, float32 stereo frames) runs k_fwd / k_inv with both channels of a block in
-    one workgroup and 16-byte frame accesses; buffers that are only 8-byte aligned fall back to one channel
-    per workgroup.  Either way: the bits of the staging kernels, for a batch of engines on device buffers."""
+    """The plug-in's shape (REALSIZE 8, float32 stereo frames) runs k_inv (and, with BFIR_RUN64=0, k_fwd) with both
+    channels of a block in one workgroup and 16-byte frame accesses; buffers that are only 8-byte aligned fall back to one
+    channel per workgroup.  Either way: the staging kernels' result (to the bit with the table twiddles, see
+    _run_kernel_twiddles), for a batch of engines on device buffers."""
     import os
     import torch
     L, B, C, nb, ne = 1024, 4, 2, 9, 3
@@ -325,7 +346,7 @@ def test_stereo_float_frames_direct_batch_and_alignment(orc, bfir, misalign):
         assert eng.sync() == 0
         outs.append(d_y[pad:pad + x.size].cpu().numpy().reshape(ne, nb * L, C))
         eng.close()
-    assert np.array_equal(outs[0], outs[1])
+    assert _same_outputs(outs[0], outs[1], 8, L, True)
     for g in range(ne):
         ref = orc.Engine(L, B, 8, C, 8, 8); ref.set_coeff(hs[g])
         assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames
@@ -362,10 +383,80 @@ def test_wide_float_frames_direct_channel_pairs(orc, bfir, C, misalign, L):
         outs.append(d_y[pad:pad + x.size].cpu().numpy().reshape(ne, nb * L, C))
         ofs.append([(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(ne * C)])
         eng.close()
-    assert np.array_equal(outs[0], outs[1]) and ofs[0] == ofs[1]
+    assert _same_outputs(outs[0], outs[1], 8, L, True) and _same_stats(ofs[0], ofs[1], 8, L)
     for g in range(ne):
         ref = orc.Engine(L, B, 8, C, 8, 8); ref.set_coeff(hs[g])
         assert rel_err(outs[0][g], ref.run(x[g])[1]) <= 1e-5      # float32 output frames
+
+
+@pytest.mark.parametrize("C,misalign,L", [(2, 0, 4096), (2, 16, 1024), (2, 0, 64), (4, 0, 1024), (6, 8, 512), (8, 16, 2048)])
+def test_float64_frames_direct_channel_pairs(orc, bfir, C, misalign, L):
+    """fp64 engines on float64 frames with an even channel count (cfg5; the plug-in's shape with REALSIZE-8 frames): k_fwd /
+    k_inv take a channel PAIR per workgroup and move whole stereo frames (32 bytes per lane) or 16 bytes of every wider
+    frame, instead of 8 bytes at the frame stride (round 3).  Same bits as the staging path -- one-block and multi-block
+    chunks, call-to-call continuation, a batch of engines, device buffers aligned for the pair path or only for the
+    one-channel kernels (misalign) -- and the oracle's sums to 1e-12."""
+    import torch
+    B, nb, ne = 3, 7, 2
+    rng = np.random.default_rng(70 + C + misalign + L)
+    hs = [orc.synth_ir(rng, C, B * L - 3, np.float64) for _ in range(ne)]
+    x = (orc.synth_audio(rng, ne * nb * L, C, np.float64) * 1.3).reshape(ne, nb * L, C)
+    pad = misalign // 8
+    d_x = torch.zeros(x.size + 4, dtype=torch.float64, device="cuda")
+    d_x[pad:pad + x.size] = torch.from_numpy(x.reshape(-1)).cuda()
+    outs, ofs = [], []
+    for direct in (None, "0"):
+        with env_override(**({} if direct is None else {"BFIR_DIRECT": direct})):
+            eng = bfir.Brutefir(L, B, 8, C, n_engines=ne)
+        eng.set_chunk(3)
+        for g in range(ne):
+            assert eng.set_coeff(hs[g], engine_index=g) == 0
+        d_y = torch.zeros(x.size + 4, dtype=torch.float64, device="cuda")
+        stride = nb * L * C * 8
+        for a, b in ((0, 4), (4, 5), (5, nb)):
+            eng.run_device(d_x.data_ptr() + misalign + a * L * C * 8, d_y.data_ptr() + misalign + a * L * C * 8, b - a,
+                           in_stride_bytes=stride, out_stride_bytes=stride)
+        assert eng.sync() == 0
+        outs.append(d_y[pad:pad + x.size].cpu().numpy().reshape(ne, nb * L, C))
+        ofs.append([(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(ne * C)])
+        eng.close()
+    assert _same_outputs(outs[0], outs[1], 8, L) and _same_stats(ofs[0], ofs[1], 8, L)
+    for g in range(ne):
+        ref = orc.Engine(L, B, 8, C); ref.set_coeff(hs[g])
+        assert rel_err(outs[0][g], ref.run(x[g])[1]) <= TOL[8]
+
+
+@pytest.mark.parametrize("L,C,fmt", [(4096, 2, 10), (2048, 3, 10), (2048, 1, 8), (8192, 1, 10), (1024, 3, 8), (1024, 2, 8), (1024, 6, 10)])
+def test_run_kernels_do_not_depend_on_the_chunking(orc, bfir, L, C, fmt):
+    """k_fwd_run / k_inv_run (fp64 engines in direct mode, 1024 <= L <= 8192, one channel per workgroup) walk runs of
+    blocks with the window's first half and the next block's data carried in registers: whatever the launch sizes -- one
+    call, single blocks (the plug-in's pattern), uneven pieces, explicit chunks shorter and longer than a run, a reset in
+    between -- every output sample has the same bits, the overflow statistics are the same, and the result is the oracle's
+    to 1e-12 (1e-5 on float32 frames).  BFIR_RUN64=0 (the one-transform kernels, table twiddles) agrees to 1e-14."""
+    B, nb = 3, 41
+    rng = np.random.default_rng(L + C + fmt)
+    h = orc.synth_ir(rng, C, B * L - 9, np.float64)
+    x = (orc.synth_audio(rng, nb * L, C, np.float64) * 1.5).astype(orc.fmt_dtype(fmt))
+
+    def run(pieces, chunk, env=None):
+        with env_override(**(env or {})):
+            eng = bfir.Brutefir(L, B, 8, C, fmt, fmt)
+            eng.set_chunk(chunk); assert eng.set_coeff(h) == 0
+            ys, a = [], 0
+            for n in pieces:
+                ys.append(eng.run(x[a * L:(a + n) * L])[1]); a += n
+            st = [(eng.overflow(c).n_overflows, eng.overflow(c).largest) for c in range(C)]
+            eng.close()
+        return np.concatenate(ys), st
+
+    y0, st0 = run([nb], 0)
+    for pieces, chunk in (([1] * nb, 0), ([5, 1, 17, 2, 16], 0), ([nb], 7), ([20, 21], 33)):
+        y, st = run(pieces, chunk)
+        assert np.array_equal(y, y0) and st == st0
+    ref = orc.Engine(L, B, 8, C, fmt, fmt); ref.set_coeff(h)
+    assert rel_err(y0, ref.run(x)[1]) <= (1e-5 if fmt == 8 else TOL[8])
+    y1, st1 = run([nb], 0, {"BFIR_RUN64": "0"})
+    assert _same_outputs(y0, y1, 8, L, fmt == 8) and _same_stats(st0, st1, 8, L)
 
 
 @pytest.mark.parametrize("s,L,B,C", [(4, 1024, 40, 2), (4, 128, 5, 3), (8, 1024, 7, 2), (4, 4096, 9, 8), (8, 64, 3, 1)])

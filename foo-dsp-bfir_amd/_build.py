@@ -1,5 +1,7 @@
 """Build libbfir_hip.so (the C-ABI library) for gfx950 with hipcc, in-tree."""
+import json
 import os
+import re
 import shutil
 import subprocess
 
@@ -24,6 +26,43 @@ def _stale(target, deps):
 
 
 FLAGS_FILE = os.path.join(LIBDIR, "flags.txt")
+USAGE_FILE = os.path.join(LIBDIR, "resource_usage.json")
+
+
+def _compile(cmd, src):
+    """One translation unit, with the compiler's per-kernel resource remarks (-Rpass-analysis=kernel-resource-usage:
+    registers, scratch, occupancy, LDS) parsed into lib/<src>.usage.json -- tests/test_isa_audit.py holds the kernels whose
+    design rests on a register budget to it (no scratch, the waves per SIMD they were built for)."""
+    r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+    usage, cur = {}, None
+    rest = []
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", ln)
+        if m:
+            cur = usage.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass-analysis", ln)
+        if m and cur is not None:
+            v = m.group(2)
+            cur[m.group(1).strip()] = int(v) if v.isdigit() else v
+            continue
+        if "-Rpass-analysis=kernel-resource-usage" not in ln and not re.match(r"^\s+(\d+ \|)|^\s+\|", ln):
+            rest.append(ln)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd, stderr="\n".join(rest))
+    with open(os.path.join(LIBDIR, os.path.basename(src) + ".usage.json"), "w") as f:
+        json.dump(usage, f, indent=0, sort_keys=True)
+
+
+def resource_usage():
+    """{mangled kernel name: {"VGPRs": n, "ScratchSize": n, "Occupancy": n, ...}} of the objects in lib/ (build() first)."""
+    out = {}
+    for src in SOURCES:
+        try:
+            out.update(json.load(open(os.path.join(LIBDIR, src + ".usage.json"))))
+        except OSError:
+            pass
+    return out
 
 
 def _flags_changed():
@@ -51,13 +90,17 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append(cmd)
+            jobs.append((cmd, src))
         objs.append(o)
     if jobs:   # the translation units are independent: compile them side by side (4 at most)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
-            for r in pool.map(lambda c: subprocess.run(c, check=True), jobs):
-                pass
+            try:
+                for r in pool.map(lambda c: _compile(*c), jobs):
+                    pass
+            except subprocess.CalledProcessError as e:
+                print(e.stderr or "")
+                raise
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
         if verbose:

@@ -26,7 +26,7 @@
 //   * the walk is forward: y[t] leaves S - 1 slots after x[t] has arrived, a run of R outputs costs R + S - 1 slots and
 //     S (PL + 1) window loads of history: short runs are cheap;
 //   * the same kernel serves fp32 (pairs layout) and fp64 (the reference's grouped layout: re and im 32 bytes apart),
-//     S PL >= B partitions: fp32 up to 128, fp64 up to 64.
+//     S PL >= B partitions: up to 128.
 // Bin 0 (DC | Nyquist: two independent real sums) is left to the first workgroups of the grid, as in k_mac_stream.
 #include "kernels.h"
 
@@ -329,7 +329,7 @@ template <typename T, int S, int PL, int D> static void launch_sys(const MacArgs
 }
 
 // fp32 on the pairs layout (whole columns of 256 / S bins: N / 2 >= 128), fp64 on the grouped layout (N / 2 >= 64 bins,
-// i.e. the engines with N >= 512 either way); S PL >= B
+// i.e. the engines with N >= 512 either way); S PL >= B: up to 128 partitions
 bool mac_sys_supported(const MacArgs &a)
 {
     if (a.N < 512) return false;
@@ -337,7 +337,7 @@ bool mac_sys_supported(const MacArgs &a)
     const unsigned long long spec = (unsigned long long)a.N * (unsigned)a.realsize;
     if (spec * (unsigned)a.ring >= (1ull << 32) || spec * (unsigned)a.n_t > (1ull << 31)) return false;
     if (a.realsize == 4) return a.interleaved && a.B <= 128;
-    return !a.interleaved && a.B <= 64;
+    return !a.interleaved && a.B <= 128;
 }
 
 void launch_mac_sys(const MacArgs &a, hipStream_t s)
@@ -351,6 +351,7 @@ void launch_mac_sys(const MacArgs &a, hipStream_t s)
     } else {
         if (a.B <= 16) launch_sys<double, 2, 8, 4>(a, s);
         else if (a.B <= 32) launch_sys<double, 2, 16, 4>(a, s);
+        else if (a.B > 64) launch_sys<double, 8, 16, 6>(a, s);   // eight stages: 65 ... 128 partitions
         else {
             // prefetch depth in slots: 6 (160 registers, three waves per SIMD) measured best, cfg5 39.7 against 39.2 (4)
             // and 39.4 (8), the plug-in's shape 43.3 / 40.1 / 43.7 (profiles/r03_fp64.txt); BFIR_SYS_D overrides

@@ -64,6 +64,7 @@ run cfg2 --workload cfg2_2ch_65536tap_L8192_fp32
 run cfg4_256streams --workload cfg4_stereo_65536tap_L4096_fp32 --streams 256
 run cfg5_fp64 --workload cfg5_2ch_262144tap_L4096_fp64
 BFIR_MAC_SYS=0 run cfg5_fp64_r02_mac --workload cfg5_2ch_262144tap_L4096_fp64
+BFIR_RUN64=0 run cfg5_fp64_one_transform_kernels --workload cfg5_2ch_262144tap_L4096_fp64
 run plugin_fp64_f32frames --workload plugin_2ch_65536tap_L1024_fp64_f32frames      # the plug-in as shipped
 BFIR_MAC_SYS=0 run plugin_fp64_f32frames_r02_mac --workload plugin_2ch_65536tap_L1024_fp64_f32frames
 run plugin_fp64_f32frames_chunk4096 --workload plugin_2ch_65536tap_L1024_fp64_f32frames --chunk 4096
@@ -71,6 +72,9 @@ run plugin_fp64_f64frames --workload plugin_2ch_65536tap_L1024_fp64
 run plugin_fp64_f32frames_8ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 8       # 7.1 audio through the shipped precision
 BFIR_DIRECT=0 run plugin_fp64_f32frames_8ch_staging --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 8
 run plugin_fp64_f32frames_6ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 6
+for C in 5 3 1; do run plugin_fp64_f32frames_${C}ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels $C; done
+BFIR_RUN64=0 run plugin_fp64_f32frames_one_transform_kernels --workload plugin_2ch_65536tap_L1024_fp64_f32frames
+BFIR_RUN64=0 run plugin_fp64_f32frames_5ch_staging_r02 --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 5
 run plugin_fp32 --workload plugin_2ch_65536tap_L1024_fp32
 run plugin_8ch_B64 --workload plugin_8ch_65536tap_L1024_fp32
 run plugin_8ch_B128 --workload plugin_8ch_131072tap_L1024_fp32

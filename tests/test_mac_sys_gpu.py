@@ -36,6 +36,8 @@ SHAPES = [
     ("d_B64_S4_L4096_wrap", 4096, 64, 2, 1, 200, [200, 200, 200], 100, {"BFIR_MAC_RANGE": "37"}),
     ("d_B20_S2", 512, 20, 3, 2, 200, [200, 200], 200, {}),
     ("d_B9_S2_PL8", 256, 9, 2, 1, 300, [300, 300], 300, {"BFIR_MAC_RANGE": "11"}),
+    ("d_B100_S8", 512, 100, 2, 1, 260, [260, 33, 260], 260, {}),
+    ("d_B128_S8_wrap", 1024, 128, 1, 2, 300, [300, 300], 150, {"BFIR_MAC_RANGE": "45"}),
 ]
 
 

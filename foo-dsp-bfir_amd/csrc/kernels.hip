@@ -5,9 +5,11 @@
 //   k_stage_in   a5   convolver_raw2cbuf            fftw_convolver.cpp:156-185
 //   k_fwd        a6+a7 time2freq + mixnscale INPUT  :187-212, :883-907 / :1583-1607
 //                a16  coeffs2cbuf (zero_first_half) :474-537
+//   k_fwd_run    a5-a7 of fp64 engines on raw frames, a run of blocks per workgroup
 //   k_mac        a8-a10 convolve / convolve_add / convolve_inplace
 //                                                   :1429-1525 / :2125-2220
 //   k_inv        a11+a12 mixnscale OUTPUT + freq2time :1163-1186, :350-375
+//   k_inv_run    a11-a13 of fp64 engines on raw frames, a run of blocks per workgroup
 //   k_stage_out  a13  convolver_cbuf2raw            :405-466, real2raw.cpp:321-420
 // All spectra in HBM use the reference's grouped layout (4 real parts, then the
 // 4 imaginary parts of the same bins; Nyquist in slot 4), so one group is two
@@ -565,9 +567,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_fwd_run(FwdArgs a, con
 // has that many blocks, never more than 8 (cfg5: 42.6 / 42.8 / 42.1 Gsamples/s at 4 / 8 / 16; short runs keep the three kernels of
 // the pipeline close together in time);
 // BFIR_RUN64 overrides (0 = the one-transform kernels)
-#ifndef BFIR_RUN64_MIN_LOG2M
-#define BFIR_RUN64_MIN_LOG2M 10
-#endif
+constexpr int BFIR_RUN64_MIN_LOG2M = 10;   // 1024 points: one wave per transform (512: half a wave, not built)
 bool run64_supported(int filter_length, int realsize)
 {
     if (const char *e = getenv("BFIR_RUN64")) if (atoi(e) == 0) return false;

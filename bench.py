@@ -456,11 +456,15 @@ def main():
     # untimed extra pass for the roofline object: the same engine configuration on a serial schedule
     exclusive = None
     if eng is not None and rank == 0 and not args.no_kernel_events and not args.no_exclusive_pass:
+        old_pipe = os.environ.get("BFIR_PIPE")
         os.environ["BFIR_PIPE"] = "1"
         try:
             ser = bfir.Brutefir(L, B, s, C, fmt, fmt, device=local, n_engines=n_eng)
         finally:
-            del os.environ["BFIR_PIPE"]
+            if old_pipe is None:
+                del os.environ["BFIR_PIPE"]
+            else:
+                os.environ["BFIR_PIPE"] = old_pipe
         ser.set_chunk(chunk)
         for k in range(n_eng):
             assert ser.set_coeff(hs[k], engine_index=k) == 0

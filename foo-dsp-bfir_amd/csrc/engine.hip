@@ -23,6 +23,7 @@
 #include <cstring>
 #include <cstdint>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bfir_hip.h"
@@ -297,8 +298,25 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         const bool wide = (e->in_bytes == 8 && e->out_bytes == 8) || channels == 1 || stereo || run64_supported(filter_length, realsize);
         e->direct = !e->pair && fmt_is_native(in_format) && fmt_is_native(out_format) && !(pv && atoi(pv) == 0) &&
                     (dv ? atoi(dv) != 0 : wide);
+        // fp64 engines whose transforms the run kernels take keep their spectra -- delay line, filter partitions, products --
+        // as (re, im) PAIRS like the fp32 engines, not in the reference's groups of four: one 16-byte access per bin in the
+        // MAC instead of two of 8, the forward kernel's spectrum straight from registers (no LDS staging), conflict-free reads
+        // in the inverse.  Only where every kernel on the engine's way reads pairs: direct mode, the systolic MAC (up to 128
+        // partitions) -- so the switches that pick other kernels keep the groups (all read HERE, at creation, for such engines).
+        // BFIR_F64_PAIRS=0: off (A/B).  Same arithmetic either way: the same bits.
+        {
+            const char *fp = getenv("BFIR_F64_PAIRS"), *ms = getenv("BFIR_MAC_SYS"), *mv = getenv("BFIR_MAC_VARIANT");
+            const bool other_mac = (ms && atoi(ms) == 0) || getenv("BFIR_MAC64_VARIANT") || getenv("BFIR_MAC_BATCHED") || (mv && atoi(mv) != 0);
+            if (realsize == 8 && e->direct && pairs64_supported(filter_length, realsize) && filter_blocks <= 128 && !other_mac &&
+                !(fp && atoi(fp) == 0))
+                e->ilv = true;
+        }
     }
     if (const char *pm = getenv("BFIR_PIPE")) { e->pipe3 = atoi(pm) >= 3; e->serial = atoi(pm) == 1; }
+    // fp64 engines: one stream.  Their kernels are bound by issue and latency, not by memory, each fills the GPU by itself, and
+    // three of them side by side only get into each other's way: the plug-in's shape 42.8 -> 45.9 Gsamples/s, 8 channels 42.5 ->
+    // 44.6, cfg5 43.1 either way (profiles/r03_fp64.txt).  The fp32 headline gains 10 % from the three-stream schedule.
+    else if (realsize == 8) { e->pipe3 = false; e->serial = true; }
     e->nblk.assign(e->GC, 0);
     e->eng_init.assign(n_engines, 0);
     int rc = fft_plan_create(&e->plan, filter_length, realsize);
@@ -482,13 +500,16 @@ extern "C" int bfir_engine_read_coeff(bfir_engine *e, int channel, int block, vo
     HIP_TRY(hipDeviceSynchronize());
     const size_t cb = cbuf_bytes(e);
     HIP_TRY(hipMemcpy(dst, (char *)e->H + ((size_t)channel * e->B + block) * cb, cb, hipMemcpyDeviceToHost));
-    if (e->ilv) {   // hand out the reference's grouped layout (fftw_convolver.cpp:883-907); ilv engines are fp32
-        std::vector<float> tmp((const float *)dst, (const float *)dst + e->N);
-        float *o = (float *)dst;
-        for (int k = 0; k < e->N / 2; k++) {
-            o[8 * (k >> 2) + (k & 3)] = tmp[2 * k];
-            o[8 * (k >> 2) + 4 + (k & 3)] = tmp[2 * k + 1];
-        }
+    if (e->ilv) {   // hand out the reference's grouped layout (fftw_convolver.cpp:883-907)
+        auto regroup = [&](auto *o) {
+            using R = typename std::remove_pointer<decltype(o)>::type;
+            std::vector<R> tmp(o, o + e->N);
+            for (int k = 0; k < e->N / 2; k++) {
+                o[8 * (k >> 2) + (k & 3)] = tmp[2 * k];
+                o[8 * (k >> 2) + 4 + (k & 3)] = tmp[2 * k + 1];
+            }
+        };
+        if (e->s == 4) regroup((float *)dst); else regroup((double *)dst);
     }
     return BFIR_OK;
 }

@@ -187,6 +187,8 @@ bool direct_stereo_supported(int filter_length, int realsize);
 // fp64 engines of 1024 ... 8192 points in direct mode: k_fwd_run / k_inv_run, runs of blocks per workgroup with the next block's
 // frames / spectrum fetched under the current transform (BFIR_RUN64=0: off; =n: blocks per run)
 bool run64_supported(int filter_length, int realsize);
+// ... and such engines may keep their spectra as (re, im) pairs (engine.hip; 1024 ... 4096 points)
+bool pairs64_supported(int filter_length, int realsize);
 struct FwdPairArgs {
     const float *raw; long eng_stride; long frame_off;   // input frames; engine stride in floats
     int C, n_eng, n_t;

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -429,7 +430,7 @@ template <int J> __device__ __forceinline__ void mul_w32(double &re, double &im)
     }
 }
 
-template <int LOG2M, typename TR>
+template <int LOG2M, typename TR, bool ILV>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_fwd_run(FwdArgs a, const double2 *__restrict__ twb,
                                                                   const double2 *__restrict__ ws, int run_len)
 {
@@ -542,22 +543,33 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_fwd_run(FwdArgs a, con
             re[e] = xr * os; im[e] = xi * os;
         });
         pin_registers(re, im);
-        __syncthreads();
-        T *ldsr = (T *)lds;
         int ty = tid; asm volatile("" : "+v"(ty));
-#pragma unroll
-        for (int e = 0; e < P; e++) {
-            const int k = F::out_index(ty, e);
-            ldsr[8 * (k >> 2) + (k & 3)] = re[e];
-            ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
-        }
-        __syncthreads();
         const __amdgpu_buffer_rsrc_t rd = run_rsrc(dch + (long)((a.base_slot + t) % a.ring) * N, (unsigned)N * 8u);
+        if constexpr (ILV) {
+            // (re, im) pairs, bin k at 16 k bytes: a lane's sixteen bins leave straight from its registers, 16 bytes each,
+            // consecutive lanes consecutive bins (bin 0: DC | Nyquist)
+            static_for<0, P>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                V2 v; v.x = re[e]; v.y = im[e];
+                run_store_v2(v, rd, (unsigned)ty * 16u, (unsigned)F::out_index(0, e) * 16u);
+            });
+        } else {
+            // the reference's groups (4 re | 4 im): through LDS, 32 bytes per lane out
+            __syncthreads();
+            T *ldsr = (T *)lds;
 #pragma unroll
-        for (int j = 0; j < P / 2; j++) {
-            const V2 *sp = (const V2 *)ldsr + 2 * (ty + j * NT);
-            run_store_v2(sp[0], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u);
-            run_store_v2(sp[1], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u + 16u);
+            for (int e = 0; e < P; e++) {
+                const int k = F::out_index(ty, e);
+                ldsr[8 * (k >> 2) + (k & 3)] = re[e];
+                ldsr[8 * (k >> 2) + 4 + (k & 3)] = im[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < P / 2; j++) {
+                const V2 *sp = (const V2 *)ldsr + 2 * (ty + j * NT);
+                run_store_v2(sp[0], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u);
+                run_store_v2(sp[1], rd, (unsigned)ty * 32u, (unsigned)(j * NT) * 32u + 16u);
+            }
         }
         // the next transform's first exchange starts with a barrier
     }
@@ -568,10 +580,17 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_fwd_run(FwdArgs a, con
 // the pipeline close together in time);
 // BFIR_RUN64 overrides (0 = the one-transform kernels)
 constexpr int BFIR_RUN64_MIN_LOG2M = 10;   // 1024 points: one wave per transform (512: half a wave, not built)
+// fp64 spectra as (re, im) pairs: up to 4096 points (at 8192 the forward run kernel would spill: 256 registers without the
+// sixteen 16-byte stores from registers)
+constexpr int BFIR_PAIRS64_MAX_LOG2M = 12;
 bool run64_supported(int filter_length, int realsize)
 {
     if (const char *e = getenv("BFIR_RUN64")) if (atoi(e) == 0) return false;
     return realsize == 8 && filter_length >= (1 << BFIR_RUN64_MIN_LOG2M) && filter_length <= 8192;
+}
+bool pairs64_supported(int filter_length, int realsize)
+{
+    return run64_supported(filter_length, realsize) && filter_length <= (1 << BFIR_PAIRS64_MAX_LOG2M);
 }
 static int run64_len(int n_t, int n_ch)
 {
@@ -596,12 +615,12 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
                 const int len = plan.twb ? run64_len(a.n_t, a.n_ch) : 0;
                 if (len > 0) {
                     const int runs = (a.n_t + len - 1) / len;
-                    if (a.raw_bytes == 4)
-                        hipLaunchKernelGGL((k_fwd_run<LOG2M, float>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
-                    else
-                        hipLaunchKernelGGL((k_fwd_run<LOG2M, double>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
+#define BFIR_LAUNCH_FWD_RUN(TR_, IL_) hipLaunchKernelGGL((k_fwd_run<LOG2M, TR_, IL_>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const double2 *)plan.twb, (const double2 *)plan.ws, len)
+                    if constexpr (LOG2M <= BFIR_PAIRS64_MAX_LOG2M) {
+                        if (a.interleaved) { if (a.raw_bytes == 4) BFIR_LAUNCH_FWD_RUN(float, true); else BFIR_LAUNCH_FWD_RUN(double, true); return; }
+                    }
+                    if (a.raw_bytes == 4) BFIR_LAUNCH_FWD_RUN(float, false); else BFIR_LAUNCH_FWD_RUN(double, false);
+#undef BFIR_LAUNCH_FWD_RUN
                     return;
                 }
             }
@@ -624,7 +643,7 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
 #undef BFIR_LAUNCH_FWD_RAW
             return;
         }
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4 || (LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= BFIR_PAIRS64_MAX_LOG2M)) {   // fp64 pairs: the run kernels' engines
             if (a.interleaved) {
                 hipLaunchKernelGGL((k_fwd<T, LOG2M, true>), dim3(items), dim3(FftCfg<LOG2M>::NT), 0, s, a,
                                    (const V2 *)plan.tw, (const V2 *)plan.ws);
@@ -807,7 +826,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
 // registers under the output phase of block t -- behind the butterflies, whose registers are free by then -- twiddles from
 // bases, the split twiddles from one table entry per thread times constant 32nd roots.  Steps, bookkeeping (overflow
 // statistics, NaN verdict: real2raw.cpp:321-336, brutefir.cpp:316-321) and output addressing are k_inv's.
-template <int LOG2M, typename TR>
+template <int LOG2M, typename TR, bool ILV>
 __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_inv_run(InvArgs a, const double2 *__restrict__ twb,
                                                                   const double2 *__restrict__ ws, int run_len)
 {
@@ -864,8 +883,14 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_inv_run(InvArgs a, con
             static_assert(F::in_index(0, e) == e * NT, "a thread's bins lie M / 16 apart");
             const int k = tl0 + e * NT;
             const int q = (k == 0) ? 0 : M - k;
-            T xr = ldsr[8 * (k >> 2) + (k & 3)] * sc, xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
-            T yr = ldsr[8 * (q >> 2) + (q & 3)] * sc, yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+            T xr, xi, yr, yi;
+            if constexpr (ILV) {
+                const V2 vx = ((const V2 *)ldsr)[k], vy = ((const V2 *)ldsr)[q];
+                xr = vx.x * sc; xi = vx.y * sc; yr = vy.x * sc; yi = vy.y * sc;
+            } else {
+                xr = ldsr[8 * (k >> 2) + (k & 3)] * sc; xi = ldsr[8 * (k >> 2) + 4 + (k & 3)] * sc;
+                yr = ldsr[8 * (q >> 2) + (q & 3)] * sc; yi = ldsr[8 * (q >> 2) + 4 + (q & 3)] * sc;
+            }
             if (k == 0) { yr = xi; xi = (T)0; yi = (T)0; }      // X_0 = (DC, 0), X_M = (Nyquist, 0)
             T wx = wbx, wy = wby;
             mul_w32<e>(wx, wy);
@@ -941,12 +966,12 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
             const bool il = sizeof(T) == 4 && a.interleaved;
             if constexpr (direct_stereo_fits<T, LOG2M>()) {
                 if (direct_stereo_ok(a.raw_bytes, (int)sizeof(T), a.C, a.raw, a.raw_eng_stride, a.frame_off) && !il) {
-                    if (a.raw_bytes == 4)
-                        hipLaunchKernelGGL((k_inv<T, LOG2M, false, float, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
-                    else
-                        hipLaunchKernelGGL((k_inv<T, LOG2M, false, T, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const V2 *)plan.tw, (const V2 *)plan.ws);
+#define BFIR_LAUNCH_INV_PAIR(TR_, IL_) hipLaunchKernelGGL((k_inv<T, LOG2M, IL_, TR_, 2>), dim3(items / 2), dim3(2 * FftCfg<LOG2M>::NT), 0, s, a, (const V2 *)plan.tw, (const V2 *)plan.ws)
+                    if constexpr (sizeof(T) == 8 && LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= BFIR_PAIRS64_MAX_LOG2M) {   // (re, im) pairs: the run kernels' engines
+                        if (a.interleaved) { if (a.raw_bytes == 4) BFIR_LAUNCH_INV_PAIR(float, true); else BFIR_LAUNCH_INV_PAIR(T, true); return; }
+                    }
+                    if (a.raw_bytes == 4) BFIR_LAUNCH_INV_PAIR(float, false); else BFIR_LAUNCH_INV_PAIR(T, false);
+#undef BFIR_LAUNCH_INV_PAIR
                     return;
                 }
             }
@@ -954,12 +979,12 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
                 const int len = plan.twb && !a.full_output ? run64_len(a.n_t, a.n_ch) : 0;
                 if (len > 0) {
                     const int runs = (a.n_t + len - 1) / len;
-                    if (a.raw_bytes == 4)
-                        hipLaunchKernelGGL((k_inv_run<LOG2M, float>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
-                    else
-                        hipLaunchKernelGGL((k_inv_run<LOG2M, double>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a,
-                                           (const double2 *)plan.twb, (const double2 *)plan.ws, len);
+#define BFIR_LAUNCH_INV_RUN(TR_, IL_) hipLaunchKernelGGL((k_inv_run<LOG2M, TR_, IL_>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const double2 *)plan.twb, (const double2 *)plan.ws, len)
+                    if constexpr (LOG2M <= BFIR_PAIRS64_MAX_LOG2M) {
+                        if (a.interleaved) { if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RUN(float, true); else BFIR_LAUNCH_INV_RUN(double, true); return; }
+                    }
+                    if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RUN(float, false); else BFIR_LAUNCH_INV_RUN(double, false);
+#undef BFIR_LAUNCH_INV_RUN
                     return;
                 }
             }
@@ -2113,7 +2138,8 @@ static void launch_mac_small(const MacArgs &a, hipStream_t s)
         if (a.interleaved) hipLaunchKernelGGL((k_mac_small<float, true, 16>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_mac_small<float, false, 16>), grid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_mac_small<double, false, 16>), grid, block, 0, s, a);
+        if (a.interleaved) hipLaunchKernelGGL((k_mac_small<double, true, 16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_mac_small<double, false, 16>), grid, block, 0, s, a);
     }
 }
 
@@ -2131,6 +2157,13 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         const char *ms = getenv("BFIR_MAC_SYS");
         const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || (a.B > 32 && a.B <= 64)) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
         if (want && mac_sys_supported(a) && !getenv("BFIR_MAC_BATCHED")) { launch_mac_sys(a, s); return; }
+        // an fp64 engine on (re, im) pairs (engine.hip picks that layout only where this kernel serves it, and looks at the
+        // same switches when it does): no other fp64 MAC kernel reads pairs
+        if (a.realsize == 8 && a.interleaved) {
+            if (mac_sys_supported(a)) launch_mac_sys(a, s);
+            else fprintf(stderr, "bfir: fp64 engine on the pairs layout outside the systolic MAC's range (B = %d): launch skipped\n", a.B);
+            return;
+        }
     }
     if (a.realsize == 4) {
         const int v = mac_variant();

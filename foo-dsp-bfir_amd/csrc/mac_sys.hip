@@ -58,15 +58,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const void *p, unsign
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 
-// One complex spectrum value of one bin.  fp32 engines keep spectra as (re, im) pairs: one 8-byte access.  fp64 engines keep
-// the reference's grouped layout (fftw_convolver.cpp:1583-1607: 4 re | 4 im per group): two 8-byte accesses 32 bytes apart.
+// One complex spectrum value of one bin.  (re, im) pairs (fp32 engines; fp64 engines on the run kernels): ONE access of 8 / 16
+// bytes.  The reference's grouped layout (fftw_convolver.cpp:1583-1607: 4 re | 4 im per group; the other fp64 engines): two
+// 8-byte accesses 32 bytes apart.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Cx { T x, y; };
-template <typename T, int AUX> __device__ __forceinline__ Cx<T> sys_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+template <typename T, bool ILV, int AUX> __device__ __forceinline__ Cx<T> sys_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     Cx<T> c;
     if constexpr (sizeof(T) == 4) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
         c.x = __uint_as_float(v.x); c.y = __uint_as_float(v.y);
+    } else if constexpr (ILV) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+        c.x = __hiloint2double((int)v.y, (int)v.x); c.y = __hiloint2double((int)v.w, (int)v.z);
     } else {
         const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
         const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 32u, soff, AUX);
@@ -74,11 +79,16 @@ template <typename T, int AUX> __device__ __forceinline__ Cx<T> sys_load(__amdgp
     }
     return c;
 }
-template <typename T, int AUX> __device__ __forceinline__ void sys_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, Cx<T> c)
+template <typename T, bool ILV, int AUX> __device__ __forceinline__ void sys_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, Cx<T> c)
 {
     if constexpr (sizeof(T) == 4) {
         u32x2 v; v.x = __float_as_uint(c.x); v.y = __float_as_uint(c.y);
         __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
+    } else if constexpr (ILV) {
+        u32x4 v;
+        v.x = (unsigned)__double2loint(c.x); v.y = (unsigned)__double2hiint(c.x);
+        v.z = (unsigned)__double2loint(c.y); v.w = (unsigned)__double2hiint(c.y);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
     } else {
         u32x2 a, b;
         a.x = (unsigned)__double2loint(c.x); a.y = (unsigned)__double2hiint(c.x);
@@ -142,7 +152,7 @@ template <int S> __device__ __forceinline__ double hand_t(double v)
 // (the last group of a run).  ONE instantiation on purpose: a second copy of the group (without the tail test) makes the
 // register allocator reconcile the window registers at the joins and costs 16+ registers (measured); the tail test is a
 // scalar compare-and-branch per slot.  tau0 = output index stage 0 works on in slot u = 0.
-template <typename T, int S, int PL, int D>
+template <typename T, bool ILV, int S, int PL, int D>
 __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL], const T (&hi)[PL], T &hand_r, T &hand_i,
                                           __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ry, unsigned &so, unsigned xstep,
                                           unsigned xwrap, unsigned kv, unsigned kvs, int tau0, int t_lo,
@@ -162,7 +172,7 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
         }
 #endif
 #if !(BFIR_SYS_EXP & 8)
-        W[(u + D) % G] = sys_load<T, (BFIR_NT_X & 2) ? 2 : 0>(rx, kv, so);   // stage 0's x[tau + D], D slots ahead
+        W[(u + D) % G] = sys_load<T, ILV, (BFIR_NT_X & 2) ? 2 : 0>(rx, kv, so);   // stage 0's x[tau + D], D slots ahead
 #else
         W[(u + D) % G].x += (T)1;
 #endif
@@ -188,10 +198,10 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
         // (kvs): the buffer range check drops their stores -- cheaper than an exec-mask round trip per slot
         if (ty >= t_lo) {                                        // scalar; ty < t_hi by the slot count of the run
             Cx<T> v; v.x = ar; v.y = ai;
-            sys_store<T, (BFIR_NT_Y & 1) ? 2 : 0>(ry, kvs, (unsigned)BFIR_YSLOT(a, ty) * xstep, v);
+            sys_store<T, ILV, (BFIR_NT_Y & 1) ? 2 : 0>(ry, kvs, (unsigned)BFIR_YSLOT(a, ty) * xstep, v);
         }
 #else
-        if (ty == -12345 && store_lane) { Cx<T> v; v.x = ar; v.y = ai; sys_store<T, 0>(ry, kv, 0, v); }
+        if (ty == -12345 && store_lane) { Cx<T> v; v.x = ar; v.y = ai; sys_store<T, ILV, 0>(ry, kv, 0, v); }
 #endif
 #if !(BFIR_SYS_EXP & 1)
         hand_r = hand_t<S>(ar); hand_i = hand_t<S>(ai);
@@ -208,11 +218,11 @@ template <typename T, int PL, int D> constexpr int sys_min_waves()
     return regs <= 64 ? 8 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
 
-template <typename T, int S, int PL, int D>
+template <typename T, bool ILV, int S, int PL, int D>
 __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(MacArgs a, int ncol, int nR, int R, int n_dc)
 {
-    constexpr bool F32 = sizeof(T) == 4;
-    constexpr int NYQ = F32 ? 1 : 4;                             // where bin 0 keeps its second real (Nyquist): pairs / grouped
+    static_assert(ILV || sizeof(T) == 8, "fp32 engines of this size keep (re, im) pairs");
+    constexpr int NYQ = ILV ? 1 : 4;                             // where bin 0 keeps its second real (Nyquist): pairs / grouped
     constexpr int BPW = 256 / S;                                 // bins per workgroup
     const int N = a.N, ring = a.ring;
     if ((int)blockIdx.x < n_dc) {
@@ -258,8 +268,8 @@ __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(Ma
     const int gc = s / ncol, col = s - gc * ncol;
     const int stage = SysLanes<S>::stage(threadIdx.x);
     const unsigned k = col * BPW + SysLanes<S>::bin(threadIdx.x);   // bin
-    // byte offset of the bin's real part inside a spectrum (its imaginary part: + 4 in pairs, + 32 in groups of four)
-    const unsigned kv = F32 ? k * 8u : ((k >> 2) * 8u + (k & 3u)) * 8u;
+    // byte offset of the bin's real part inside a spectrum (its imaginary part: + sizeof(T) in pairs, + 32 in groups of four)
+    const unsigned kv = ILV ? k * 2u * (unsigned)sizeof(T) : ((k >> 2) * 8u + (k & 3u)) * 8u;
     const T *__restrict__ Hc = (const T *)a.h + (long)gc * a.h_ch_stride;
     const int nb = a.nblk[gc];
     const int t_lo = r * R, t_hi = min(a.n_t, t_lo + R);       // this run's outputs
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(Ma
         const int pg = stage * PL + p;
         if (pg < nb) {
             const T *hp = (const T *)((const char *)(Hc + (long)pg * N) + kv);
-            hr[p] = hp[0]; hi[p] = hp[F32 ? 1 : 4];
+            hr[p] = hp[0]; hi[p] = hp[NYQ];
         } else { hr[p] = 0; hi[p] = 0; }
     }
     // Before the first slot every lane fetches its own history: in slot tau stage j has x[tau - j (PL + 1)] as its newest
@@ -290,23 +300,23 @@ __global__ __launch_bounds__(256, (sys_min_waves<T, PL, D>())) void k_mac_sys(Ma
     constexpr int G = PL + D;
     Cx<T> W[G];
 #pragma unroll
-    for (int p = 1; p <= PL; p++) W[G - p] = sys_load<T, 0>(rx, slot_of(s0 - p) * xstep + kv, 0);
+    for (int p = 1; p <= PL; p++) W[G - p] = sys_load<T, ILV, 0>(rx, slot_of(s0 - p) * xstep + kv, 0);
 #pragma unroll
-    for (int d = 0; d < D; d++) W[d] = sys_load<T, 0>(rx, slot_of(s0 + d) * xstep + kv, 0);
+    for (int d = 0; d < D; d++) W[d] = sys_load<T, ILV, 0>(rx, slot_of(s0 + d) * xstep + kv, 0);
     unsigned so = __builtin_amdgcn_readfirstlane(slot_of(t_lo + D) * xstep);   // stage 0's time from here on: wave-uniform
     T hand_r = 0, hand_i = 0;
     const bool store_lane = stage == S - 1 && k != 0;          // bin 0 belongs to the DC / Nyquist workgroups
     const unsigned kvs = store_lane ? kv : 0x80000000u;        // out of range: mac_sys_supported keeps the buffers below 2 GiB
     int left = t_hi - t_lo + (S - 1);                           // slots: the last output leaves the top stage S - 1 slots later
     for (int tau = t_lo; left > 0; tau += G, left -= G)
-        sys_group<T, S, PL, D>(W, hr, hi, hand_r, hand_i, rx, ry, so, xstep, xwrap, kv, kvs, tau, t_lo, store_lane, left, a);
+        sys_group<T, ILV, S, PL, D>(W, hr, hi, hand_r, hand_i, rx, ry, so, xstep, xwrap, kv, kvs, tau, t_lo, store_lane, left, a);
 }
 
 }  // namespace
 
 // runs per (channel, bin column): enough workgroups for the waves per SIMD the kernel is built for, in one round
 // (BFIR_MAC_RANGE overrides the run length, in blocks; BFIR_SYS_WGS the workgroups in flight)
-template <typename T, int S, int PL, int D> static void launch_sys(const MacArgs &a_, hipStream_t s)
+template <typename T, bool ILV, int S, int PL, int D> static void launch_sys(const MacArgs &a_, hipStream_t s)
 {
     MacArgs a = a_;
 #ifdef BFIR_EXPERIMENT_ALIAS
@@ -325,7 +335,7 @@ template <typename T, int S, int PL, int D> static void launch_sys(const MacArgs
     }
     const int nR = (a.n_t + R - 1) / R;
     const int n_dc = a.n_ch * ((a.n_t + 255) / 256);
-    hipLaunchKernelGGL((k_mac_sys<T, S, PL, D>), dim3(n_dc + nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, R, n_dc);
+    hipLaunchKernelGGL((k_mac_sys<T, ILV, S, PL, D>), dim3(n_dc + nR * ncol * a.n_ch), dim3(256), 0, s, a, ncol, nR, R, n_dc);
 }
 
 // fp32 on the pairs layout (whole columns of 256 / S bins: N / 2 >= 128), fp64 on the grouped layout (N / 2 >= 64 bins,
@@ -337,31 +347,35 @@ bool mac_sys_supported(const MacArgs &a)
     const unsigned long long spec = (unsigned long long)a.N * (unsigned)a.realsize;
     if (spec * (unsigned)a.ring >= (1ull << 32) || spec * (unsigned)a.n_t > (1ull << 31)) return false;
     if (a.realsize == 4) return a.interleaved && a.B <= 128;
-    return !a.interleaved && a.B <= 128;
+    return a.B <= 128;                                       // fp64: either layout
+}
+
+template <bool ILV> static void launch_sys_f64(const MacArgs &a, hipStream_t s)
+{
+    if (a.B <= 16) launch_sys<double, ILV, 2, 8, 4>(a, s);
+    else if (a.B <= 32) launch_sys<double, ILV, 2, 16, 4>(a, s);
+    else if (a.B > 64) launch_sys<double, ILV, 8, 16, 6>(a, s);   // eight stages: 65 ... 128 partitions
+    else {
+        // prefetch depth in slots: 6 (160 registers, three waves per SIMD) measured best, cfg5 39.7 against 39.2 (4)
+        // and 39.4 (8), the plug-in's shape 43.3 / 40.1 / 43.7 (profiles/r03_fp64.txt); BFIR_SYS_D overrides
+        const char *de = getenv("BFIR_SYS_D");
+        const int d = de ? atoi(de) : 6;
+        if (d >= 8) launch_sys<double, ILV, 4, 16, 8>(a, s);
+        else if (d == 6) launch_sys<double, ILV, 4, 16, 6>(a, s);
+        else launch_sys<double, ILV, 4, 16, 4>(a, s);
+    }
 }
 
 void launch_mac_sys(const MacArgs &a, hipStream_t s)
 {
     if (a.realsize == 4) {
-        if (a.B <= 8) launch_sys<float, 2, 4, 4>(a, s);
-        else if (a.B <= 16) launch_sys<float, 2, 8, 4>(a, s);
-        else if (a.B <= 32) launch_sys<float, 2, 16, 4>(a, s);
-        else if (a.B <= 64) launch_sys<float, 4, 16, 4>(a, s);
-        else launch_sys<float, 8, 16, 4>(a, s);
-    } else {
-        if (a.B <= 16) launch_sys<double, 2, 8, 4>(a, s);
-        else if (a.B <= 32) launch_sys<double, 2, 16, 4>(a, s);
-        else if (a.B > 64) launch_sys<double, 8, 16, 6>(a, s);   // eight stages: 65 ... 128 partitions
-        else {
-            // prefetch depth in slots: 6 (160 registers, three waves per SIMD) measured best, cfg5 39.7 against 39.2 (4)
-            // and 39.4 (8), the plug-in's shape 43.3 / 40.1 / 43.7 (profiles/r03_fp64.txt); BFIR_SYS_D overrides
-            const char *de = getenv("BFIR_SYS_D");
-            const int d = de ? atoi(de) : 6;
-            if (d >= 8) launch_sys<double, 4, 16, 8>(a, s);
-            else if (d == 6) launch_sys<double, 4, 16, 6>(a, s);
-            else launch_sys<double, 4, 16, 4>(a, s);
-        }
-    }
+        if (a.B <= 8) launch_sys<float, true, 2, 4, 4>(a, s);
+        else if (a.B <= 16) launch_sys<float, true, 2, 8, 4>(a, s);
+        else if (a.B <= 32) launch_sys<float, true, 2, 16, 4>(a, s);
+        else if (a.B <= 64) launch_sys<float, true, 4, 16, 4>(a, s);
+        else launch_sys<float, true, 8, 16, 4>(a, s);
+    } else if (a.interleaved) launch_sys_f64<true>(a, s);
+    else launch_sys_f64<false>(a, s);
 }
 
 }  // namespace bfir

@@ -86,10 +86,11 @@ def test_register_budgets_of_the_persistent_kernels():
         assert got, pattern
         return got
 
-    for pattern, min_occ, n in ((r"k_(fwd|inv)_run", 2, 16),                      # 1024 ... 8192 points x float / double frames
+    for pattern, min_occ, n in ((r"k_(fwd|inv)_run", 2, 28),                      # 1024 ... 8192 points x float / double frames x spectrum layouts (pairs up to 4096)
                                 (r"k_(fwd|inv)_(pair|tp)_ps", 3, 20),
-                                (r"k_mac_sysIfLi2ELi16ELi4E", 6, 1), (r"k_mac_sysIfLi4ELi16ELi4E", 6, 1),
-                                (r"k_mac_sysIdLi4ELi16ELi6E", 3, 1), (r"k_mac_sysIdLi2ELi16ELi4E", 3, 1)):
+                                (r"k_mac_sysIfLb1ELi2ELi16ELi4E", 6, 1), (r"k_mac_sysIfLb1ELi4ELi16ELi4E", 6, 1),
+                                (r"k_mac_sysIdLb[01]ELi4ELi16ELi6E", 3, 2), (r"k_mac_sysIdLb[01]ELi2ELi16ELi4E", 3, 2),   # fp64: both spectrum layouts
+                                (r"k_mac_sysIdLb[01]ELi8ELi16ELi6E", 3, 2)):
         ks = pick(pattern)
         assert n is None or len(ks) == n, (pattern, sorted(ks))
         for name, r in ks.items():

@@ -11,10 +11,11 @@
 //   k_inv        a11+a12 mixnscale OUTPUT + freq2time :1163-1186, :350-375
 //   k_inv_run    a11-a13 of fp64 engines on raw frames, a run of blocks per workgroup
 //   k_stage_out  a13  convolver_cbuf2raw            :405-466, real2raw.cpp:321-420
-// All spectra in HBM use the reference's grouped layout (4 real parts, then the
-// 4 imaginary parts of the same bins; Nyquist in slot 4), so one group is two
-// 16-byte vectors and every stage-level buffer is bit-compatible with a
-// reference cbuf.
+// Stage-level buffers use the reference's grouped layout (4 real parts, then the
+// 4 imaginary parts of the same bins; Nyquist in slot 4): one group is two
+// 16-byte vectors, bit-compatible with a reference cbuf.  An ENGINE's internal
+// spectra are (re, im) pairs instead where its kernels read them (fp32 from 512
+// points; fp64 on the run kernels): FwdArgs / MacArgs / InvArgs .interleaved.
 #include "kernels.h"
 
 #include <algorithm>
@@ -2148,8 +2149,8 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     if (a.n_t <= 0 || a.n_ch <= 0) return;
     const int tt = a.n_t;
     if (tt <= BFIR_MAC_SMALL_MAX && !getenv("BFIR_NO_MAC_SMALL")) { launch_mac_small(a, s); return; }   // env: A/B and tests
-    {   // The forward-walking systolic kernel (mac_sys.hip: fp32 pairs layout up to 128 partitions, fp64 grouped layout
-        // up to 64): the default for fp64 (cfg5 +14 %, its MAC -20 % against the LDS-tiled kernel) and for fp32 with 33 to
+    {   // The forward-walking systolic kernel (mac_sys.hip: up to 128 partitions; fp32 on the pairs layout, fp64 on either):
+        // the default for fp64 (cfg5 +14 %, its MAC -27 % against the LDS-tiled kernel) and for fp32 with 33 to
         // 64 partitions (+1..5 % against k_mac_lds; with eight lanes per bin, 65 to 128 partitions, it is 10 % SLOWER:
         // 44.7 against 49.6 Gsamples/s at 8 channels x 128 partitions of 1024); with up to 32 partitions k_mac_stream stays
         // ahead (0.49 against 0.59 ms per 4096 headline blocks: two lanes per bin double the vector-memory instructions

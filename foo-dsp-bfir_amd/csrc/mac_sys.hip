@@ -8,7 +8,7 @@
 // has to walk the delay line backwards, a whole range of blocks at a time; the fp64 kernels share operands through LDS
 // tiles or keep 16 running sums per lane.  All of them issue their FMAs with a fresh accumulator AND a fresh operand pair
 // per instruction, the slowest operand pattern of the SIMD (scripts/ubench/fma_chain.hip: 1.35 ns per wave-FMA with 16 sums
-// per wave, 0.95-1.05 with two to four; fp64 2.78 against 1.9).  Here S ADJACENT lanes share a bin:
+// per wave, 0.95-1.05 with two to four; fp64 2.78 against 1.9).  Here S lanes of one 16-lane DPP row share a bin:
 //
 //     lane j of a group ("stage j") holds h[j PL .. (j+1) PL - 1] and a window of PL delay-line values, j (PL + 1) blocks
 //     behind stage 0's.
@@ -25,8 +25,8 @@
 //     (x 2 for double): 80-90 (fp32, PL = 16) instead of 168;
 //   * the walk is forward: y[t] leaves S - 1 slots after x[t] has arrived, a run of R outputs costs R + S - 1 slots and
 //     S (PL + 1) window loads of history: short runs are cheap;
-//   * the same kernel serves fp32 (pairs layout) and fp64 (the reference's grouped layout: re and im 32 bytes apart),
-//     S PL >= B partitions: up to 128.
+//   * the same kernel serves fp32 (pairs layout) and fp64 (pairs, or the reference's grouped layout: re and im 32 bytes
+//     apart), S PL >= B partitions: up to 128.
 // Bin 0 (DC | Nyquist: two independent real sums) is left to the first workgroups of the grid, as in k_mac_stream.
 #include "kernels.h"
 

@@ -613,7 +613,8 @@ template <typename T, int LOG2M> static void launch_fwd_t(const FftPlan &plan, c
             // blocks of the plug-in's shape) and in the pipeline (41.9 against 40.7 Gsamples/s at 8 channels); the INVERSE keeps
             // the channel pairs where it can, whole output frames beating stores at a stride (profiles/r03_fp64.txt)
             if constexpr (sizeof(T) == 8 && LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= 13) {
-                const int len = plan.twb ? run64_len(a.n_t, a.n_ch) : 0;
+                int len = plan.twb ? run64_len(a.n_t, a.n_ch) : 0;
+                if (len <= 0 && a.interleaved && plan.twb) len = 8;   // an engine on the pairs layout: only this kernel writes it (BFIR_RUN64 is read at creation)
                 if (len > 0) {
                     const int runs = (a.n_t + len - 1) / len;
 #define BFIR_LAUNCH_FWD_RUN(TR_, IL_) hipLaunchKernelGGL((k_fwd_run<LOG2M, TR_, IL_>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const double2 *)plan.twb, (const double2 *)plan.ws, len)
@@ -977,7 +978,8 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
                 }
             }
             if constexpr (sizeof(T) == 8 && LOG2M >= BFIR_RUN64_MIN_LOG2M && LOG2M <= 13) {
-                const int len = plan.twb && !a.full_output ? run64_len(a.n_t, a.n_ch) : 0;
+                int len = plan.twb && !a.full_output ? run64_len(a.n_t, a.n_ch) : 0;
+                if (len <= 0 && a.interleaved && plan.twb && !a.full_output) len = 8;   // pairs layout: the one-transform kernels below read groups
                 if (len > 0) {
                     const int runs = (a.n_t + len - 1) / len;
 #define BFIR_LAUNCH_INV_RUN(TR_, IL_) hipLaunchKernelGGL((k_inv_run<LOG2M, TR_, IL_>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const double2 *)plan.twb, (const double2 *)plan.ws, len)

@@ -160,6 +160,7 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
 {
     constexpr int G = PL + D;
     static_assert(D >= 2, "entry u + 1 and entry u + D are different registers");
+    static_assert(G >= S - 1, "only a run's first group has slots without a finished output");
     static_for<0, G>([&](auto U) {
         constexpr int u = decltype(U)::value;
 #if !(BFIR_SYS_EXP & 32)
@@ -196,7 +197,9 @@ __device__ __forceinline__ void sys_group(Cx<T> (&W)[PL + D], const T (&hr)[PL],
 #if !(BFIR_SYS_EXP & 4)
         // the lanes below the top stage (and bin 0) carry a byte offset beyond the end of every product-spectra buffer
         // (kvs): the buffer range check drops their stores -- cheaper than an exec-mask round trip per slot
-        if (ty >= t_lo) {                                        // scalar; ty < t_hi by the slot count of the run
+        // ty < t_lo only in the first S - 1 slots of a run's first group (the chain is still filling); ty < t_hi by the slot
+        // count of the run.  A compile-time test for all other slots: every scalar instruction of a slot costs issue time here
+        if (u >= S - 1 || tau0 != t_lo) {
             Cx<T> v; v.x = ar; v.y = ai;
             sys_store<T, ILV, (BFIR_NT_Y & 1) ? 2 : 0>(ry, kvs, (unsigned)BFIR_YSLOT(a, ty) * xstep, v);
         }

@@ -53,9 +53,12 @@ def test_run_matches_oracle(orc, bfir, s, L, B, C, taps, nb, chunk):
     eng.close()
 
 
-@pytest.mark.parametrize("s", [4, 8])
-def test_partition_spectra_match_oracle(orc, bfir, s):
-    L, B, C, taps = 512, 5, 2, 2100   # ragged tail: block 4 holds 52 taps
+@pytest.mark.parametrize("s,L", [(4, 512), (8, 512), (8, 1024), (8, 4096), (4, 4096)])
+def test_partition_spectra_match_oracle(orc, bfir, s, L):
+    """The partition spectra as bfir_engine_read_coeff hands them out -- in the reference's grouped layout whatever the
+    engine keeps internally ((re, im) pairs: fp32 from 256 points, fp64 on the run kernels from 1024)."""
+    B, C = 5, 2
+    taps = 4 * L + 52                 # ragged tail: block 4 holds 52 taps
     h, _ = _make(orc, s, C, taps, L, seed=11)
     ref = orc.Engine(L, B, s, C)
     ref.set_coeff(h, scale=0.5)

@@ -11,8 +11,8 @@ from . import _build
 SAMPLE_FORMAT_FLOAT_LE = 8
 SAMPLE_FORMAT_FLOAT64_LE = 10
 MIXMODE_INPUT, MIXMODE_INPUT_ADD, MIXMODE_OUTPUT = 1, 2, 3
-OK, ERR_NONFINITE, ERR_COEFF, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = (
-    0, -1, -2, -3, -4, -5, -6, -7)
+OK, ERR_NONFINITE, ERR_COEFF, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_IO = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8)
 K_STAGE_IN, K_FWD, K_MAC, K_INV, K_STAGE_OUT = range(5)
 KERNEL_NAMES = ("k_stage_in", "k_fwd", "k_mac", "k_inv", "k_stage_out")
 
@@ -91,6 +91,13 @@ SIGNATURES = {
     "bfir_convolver_convolve_eval": (_ci, [_vp, _vp, _vp, _vp]),
     "bfir_convolver_crossfade_inplace": (_ci, [_vp, _vp, _vp, _vp]),
     "bfir_convolver_verify_cbuf": (_ci, [_vp, C.POINTER(_vp), _ci]),
+    "bfir_convolver_debug_dump_cbuf": (_ci, [_vp, C.c_char_p, C.POINTER(_vp), _ci]),
+    "bfir_td_block_length": (_ci, [_ci]),
+    "bfir_td_new": (_vp, [_vp, _ci, _ci, _ci, _pi]),
+    "bfir_td_destroy": (None, [_vp]),
+    "bfir_td_blocklen": (_ci, [_vp]),
+    "bfir_td_coeffs": (_vp, [_vp]),
+    "bfir_td_convolve": (_ci, [_vp, _vp]),
     "bfir_fft_plan_create": (_vp, [_ci, _ci, _ci, _ci, _ci, _pi]),
     "bfir_fft_plan_destroy": (None, [_vp]),
     "bfir_fft_plan_execute": (_ci, [_vp, _vp, _vp]),

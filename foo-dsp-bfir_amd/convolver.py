@@ -50,6 +50,29 @@ class Dither:
         return np.ctypeslib.as_array(self._lib.bfir_dither_table(self._h), shape=(n,)).copy()
 
 
+class TdConv:
+    """td_conv_t (brutefir/fftw_convolver.hpp:18-26) as convolver_td_new returns it: `coeffs` is the host copy of the
+    scaled half-complex spectrum, `blocklen` the block length; the spectrum the product reads stays on the device."""
+
+    def __init__(self, lib, handle, dtype):
+        self._lib, self._h = lib, handle
+        self.blocklen = lib.bfir_td_blocklen(handle)
+        n = 2 * self.blocklen
+        src = (C.c_float if dtype == np.float32 else C.c_double) * n
+        self.coeffs = np.frombuffer(src.from_address(lib.bfir_td_coeffs(handle)), dtype=dtype).copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bfir_td_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FftwConvolver:
     """fftw_convolver(length, realsize, dither) (brutefir/fftw_convolver.hpp:31).  `dither` (a Dither)
     is only needed for convolver_cbuf2raw with apply_dither on an integer format."""
@@ -57,7 +80,7 @@ class FftwConvolver:
     def __init__(self, length, realsize, dither=None, device=0):
         self._lib = _lib.load()
         self._dither = dither
-        self.n_fft2, self.n_fft, self.realsize = length, 2 * length, realsize
+        self.n_fft2, self.n_fft, self.realsize, self.device = length, 2 * length, realsize, device
         self.dtype = np.float32 if realsize == 4 else np.float64
         err = C.c_int(0)
         self._h = self._lib.bfir_convolver_create(length, realsize, device, C.byref(err))
@@ -170,3 +193,32 @@ class FftwConvolver:
         if rc < 0:
             raise BfirError(rc, "verify_cbuf")
         return bool(rc)
+
+    def convolver_debug_dump_cbuf(self, filename, cbufs, n_cbufs):
+        """Text dump of the coefficient lists behind `cbufs` (brutefir/fftw_convolver.cpp:604-651).  A file that
+        cannot be opened is logged and skipped, as there (the method is void)."""
+        ptrs = (C.c_void_p * n_cbufs)(*[self._buf(b) for b in cbufs[:n_cbufs]])
+        rc = self._lib.bfir_convolver_debug_dump_cbuf(self._h, str(filename).encode(), ptrs, n_cbufs)
+        if rc not in (_lib.OK, _lib.ERR_IO):
+            raise BfirError(rc, "debug_dump_cbuf")
+
+    # ---- the td convolver of the (dead) delay class (fftw_convolver.hpp:157-166) ----
+    def convolver_td_block_length(self, n_coeffs):
+        return self._lib.bfir_td_block_length(int(n_coeffs))
+
+    def convolver_td_new(self, coeffs, n_coeffs):
+        """Returns a TdConv, or None where the reference returns NULL (block length -1)."""
+        if self.convolver_td_block_length(n_coeffs) == -1:
+            return None
+        taps = np.ascontiguousarray(coeffs, dtype=self.dtype)
+        assert taps.size >= n_coeffs
+        err = C.c_int(0)
+        h = self._lib.bfir_td_new(taps.ctypes.data, int(n_coeffs), self.realsize, self.device, C.byref(err))
+        if not h:
+            raise BfirError(err.value, "bfir_td_new")
+        return TdConv(self._lib, h, self.dtype)
+
+    def convolver_td_convolve(self, tdc, overlap_block):
+        assert overlap_block.dtype == self.dtype and overlap_block.flags.c_contiguous
+        assert overlap_block.size >= 2 * tdc.blocklen
+        self._chk(self._lib.bfir_td_convolve(tdc._h, overlap_block.ctypes.data), "td_convolve")

@@ -122,6 +122,57 @@ template <typename T> __global__ void k_z_to_hc(const typename Vec2<T>::type *__
     if (q != k) { hc[q] = er - tr; hc[n - q] = -(ei - ti); }
 }
 
+// Transforms of 2 ... 16 reals (plans of order 1 ... 4: the td convolver of a filter of up to eight taps,
+// fftw_convolver.cpp:726-727) are below the workgroup FFT's smallest size: one lane per output, the
+// defining sums in double.
+template <typename T> __global__ void k_small_r2hc(const T *__restrict__ x, T *__restrict__ hc, int n)
+{
+    const int k = threadIdx.x;
+    if (k > n / 2) return;
+    double re = 0.0, im = 0.0;
+    for (int j = 0; j < n; j++) {
+        double sn, cs;
+        sincospi(2.0 * (double)((j * k) % n) / (double)n, &sn, &cs);
+        re += (double)x[j] * cs; im -= (double)x[j] * sn;
+    }
+    hc[k] = (T)re;
+    if (k > 0 && k < n / 2) hc[n - k] = (T)im;
+}
+
+template <typename T> __global__ void k_small_hc2r(const T *__restrict__ hc, T *__restrict__ x, int n)
+{
+    const int j = threadIdx.x;
+    if (j >= n) return;
+    double acc = (double)hc[0] + ((j & 1) ? -(double)hc[n / 2] : (double)hc[n / 2]);
+    for (int k = 1; k < n / 2; k++) {
+        double sn, cs;
+        sincospi(2.0 * (double)((j * k) % n) / (double)n, &sn, &cs);
+        acc += 2.0 * ((double)hc[k] * cs - (double)hc[n - k] * sn);
+    }
+    x[j] = (T)acc;
+}
+
+// every value times sc (convolver_td_new's normalisation, fftw_convolver.cpp:740-753)
+template <typename T> __global__ void k_hc_scale(T *__restrict__ a, T sc, long n)
+{
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] *= sc;
+}
+
+// convolve_inplace_ordered (fftw_convolver.cpp:819-856): half-complex product in place in b, the
+// reference's separate multiplies and adds
+template <typename T> __global__ void k_hc_mul_ordered(T *__restrict__ b, const T *__restrict__ c, long size)
+{
+#pragma clang fp contract(off)
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x, size2 = size >> 1;
+    if (n > size2) return;
+    if (n == 0 || n == size2) { b[n] *= c[n]; return; }
+    const T a = b[n], bi = b[size - n];
+    b[n] = a * c[n] - bi * c[size - n];
+    b[size - n] = a * c[size - n] + bi * c[n];
+}
+
 #define BFIR_ROWS_CASE(lg)                                                                                  \
     case lg:                                                                                                \
         if (sign < 0) hipLaunchKernelGGL((k_cfft_rows<T, lg, -1>), dim3(rows), dim3(FftCfg<lg>::NT), 0, s,  \
@@ -167,7 +218,7 @@ extern "C" bfir_fft_plan *bfir_fft_plan_create(int order, int invert, int inplac
     int dummy;
     if (!err) err = &dummy;
     *err = BFIR_OK;
-    if ((realsize != 4 && realsize != 8) || order < 5 || order > 25) { *err = BFIR_ERR_ARG; return nullptr; }
+    if ((realsize != 4 && realsize != 8) || order < 1 || order > 25) { *err = BFIR_ERR_ARG; return nullptr; }
     int ndev = bfir_device_count();
     if (ndev <= 0) { *err = BFIR_ERR_NO_DEVICE; return nullptr; }
     if (device < 0 || device >= ndev) { *err = BFIR_ERR_ARG; return nullptr; }
@@ -176,10 +227,11 @@ extern "C" bfir_fft_plan *bfir_fft_plan_create(int order, int invert, int inplac
     p->device = device; p->order = order; p->invert = invert ? 1 : 0; p->realsize = realsize;
     p->n = 1L << order;
     const int lm = order - 1;                       // complex points
-    if (lm <= 12) { p->lm1 = lm; p->lm2 = 0; }
+    if (order < 5) { p->lm1 = 0; p->lm2 = 0; }      // direct sums (k_small_*)
+    else if (lm <= 12) { p->lm1 = lm; p->lm2 = 0; }
     else { p->lm1 = (lm + 1) / 2; p->lm2 = lm - p->lm1; }
     if (p->lm1 > 12 || (p->lm2 != 0 && p->lm2 < 4)) { *err = BFIR_ERR_UNSUPPORTED; delete p; return nullptr; }
-    bool ok = fft_plan_create(&p->p1, 1 << p->lm1, realsize) == 0;
+    bool ok = order < 5 || fft_plan_create(&p->p1, 1 << p->lm1, realsize) == 0;
     if (ok && p->lm2) ok = fft_plan_create(&p->p2, 1 << p->lm2, realsize) == 0;
     ok = ok && hipMalloc(&p->d_a, (size_t)p->n * realsize) == hipSuccess;
     ok = ok && hipMalloc(&p->d_b, (size_t)p->n * realsize) == hipSuccess;
@@ -220,22 +272,45 @@ template <typename T> static void complex_fft(bfir_fft_plan *p, int sign)
     (void)hipMemcpyAsync(p->d_a, p->d_b, (size_t)M * 2 * sizeof(T), hipMemcpyDeviceToDevice, s);
 }
 
+// FFTW_R2HC of the n reals in d_a -> half-complex in d_b (d_a is overwritten)
+template <typename T> static void r2hc_dev(bfir_fft_plan *p)
+{
+    const int threads = 256, M = (int)(p->n >> 1);
+    hipStream_t s = p->stream;
+    if (p->order < 5) {
+        hipLaunchKernelGGL(k_small_r2hc<T>, dim3(1), dim3(64), 0, s, (const T *)p->d_a, (T *)p->d_b, (int)p->n);
+        return;
+    }
+    complex_fft<T>(p, -1);
+    hipLaunchKernelGGL(k_z_to_hc<T>, dim3((M / 2 + 1 + threads - 1) / threads), dim3(threads), 0, s,
+                       (const typename Vec2<T>::type *)p->d_a, (T *)p->d_b, (int)p->n);
+}
+
+// FFTW_HC2R (unnormalised) of the half-complex values in d_b -> n reals in d_a
+template <typename T> static void hc2r_dev(bfir_fft_plan *p)
+{
+    const int threads = 256, M = (int)(p->n >> 1);
+    hipStream_t s = p->stream;
+    if (p->order < 5) {
+        hipLaunchKernelGGL(k_small_hc2r<T>, dim3(1), dim3(64), 0, s, (const T *)p->d_b, (T *)p->d_a, (int)p->n);
+        return;
+    }
+    hipLaunchKernelGGL(k_hc_to_z<T>, dim3((M + threads - 1) / threads), dim3(threads), 0, s, (const T *)p->d_b,
+                       (typename Vec2<T>::type *)p->d_a, (int)p->n);
+    complex_fft<T>(p, +1);                               // z[m] = (x[2m], x[2m+1])
+}
+
 template <typename T> static int execute_t(bfir_fft_plan *p, const void *in, void *out)
 {
     const size_t bytes = (size_t)p->n * sizeof(T);
-    const int threads = 256, M = (int)(p->n >> 1);
     hipStream_t s = p->stream;
-    if (p->invert) {   // FFTW_HC2R: unnormalised inverse
+    if (p->invert) {
         HIP_TRY(hipMemcpyAsync(p->d_b, in, bytes, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_hc_to_z<T>, dim3((M + threads - 1) / threads), dim3(threads), 0, s, (const T *)p->d_b,
-                           (typename Vec2<T>::type *)p->d_a, (int)p->n);
-        complex_fft<T>(p, +1);                           // z[m] = (x[2m], x[2m+1])
+        hc2r_dev<T>(p);
         HIP_TRY(hipMemcpyAsync(out, p->d_a, bytes, hipMemcpyDeviceToHost, s));
-    } else {           // FFTW_R2HC
+    } else {
         HIP_TRY(hipMemcpyAsync(p->d_a, in, bytes, hipMemcpyHostToDevice, s));
-        complex_fft<T>(p, -1);
-        hipLaunchKernelGGL(k_z_to_hc<T>, dim3((M / 2 + 1 + threads - 1) / threads), dim3(threads), 0, s,
-                           (const typename Vec2<T>::type *)p->d_a, (T *)p->d_b, (int)p->n);
+        r2hc_dev<T>(p);
         HIP_TRY(hipMemcpyAsync(out, p->d_b, bytes, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -252,6 +327,106 @@ extern "C" int bfir_fft_plan_execute(bfir_fft_plan *p, const void *in, void *out
 }
 
 extern "C" int64_t bfir_fft_plan_length(const bfir_fft_plan *p) { return p ? p->n : 0; }
+
+// ---------------------------------------------------------------------------
+// fftw_convolver::convolver_td_* (brutefir/fftw_convolver.hpp:157-166, fftw_convolver.cpp:697-777):
+// the small one-block convolver the reference's (unused) delay class filters its sub-sample
+// delays with (delay.cpp:174, 196, 240-257)
+// ---------------------------------------------------------------------------
+struct bfir_td_conv {
+    bfir_fft_plan *plan = nullptr;   // 2 * blocklen reals; its two buffers carry both directions
+    void *d_coeffs = nullptr;        // half-complex spectrum of [0 ... 0 | taps | 0 ...], times 1 / (2 blocklen)
+    void *h_coeffs = nullptr;        // host copy: td_conv_t.coeffs
+    int blocklen = 0;
+};
+
+// log2_roof (brutefir/log2.h:33-51) of n_coeffs as a power of two.  The reference's log2_roof(1) is -1 and it
+// then shifts by that (undefined); here one tap is refused like zero taps.
+extern "C" int bfir_td_block_length(int n_coeffs)
+{
+    if (n_coeffs < 2 || n_coeffs > (1 << 24)) return -1;
+    int lg = 0;
+    while ((1 << lg) < n_coeffs) lg++;
+    return 1 << lg;
+}
+
+template <typename T> static int td_new_t(bfir_td_conv *t, const void *coeffs, int n_coeffs)
+{
+    bfir_fft_plan *p = t->plan;
+    const size_t n = (size_t)p->n, bl = (size_t)t->blocklen;
+    hipStream_t s = p->stream;
+    HIP_TRY(hipMemsetAsync(p->d_a, 0, n * sizeof(T), s));
+    HIP_TRY(hipMemcpyAsync((T *)p->d_a + bl, coeffs, (size_t)n_coeffs * sizeof(T), hipMemcpyHostToDevice, s));
+    r2hc_dev<T>(p);
+    const T sc = (T)(1.0 / (T)(t->blocklen << 1));
+    hipLaunchKernelGGL(k_hc_scale<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (T *)p->d_b, sc, (long)n);
+    HIP_TRY(hipMemcpyAsync(t->d_coeffs, p->d_b, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->h_coeffs, p->d_b, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    return BFIR_OK;
+}
+
+extern "C" void bfir_td_destroy(bfir_td_conv *t)
+{
+    if (!t) return;
+    if (t->plan) {
+        (void)hipSetDevice(t->plan->device);
+        if (t->d_coeffs) { (void)hipDeviceSynchronize(); (void)hipFree(t->d_coeffs); }
+        bfir_fft_plan_destroy(t->plan);
+    }
+    if (t->h_coeffs) bfir_aligned_free(t->h_coeffs);
+    delete t;
+}
+
+extern "C" bfir_td_conv *bfir_td_new(const void *coeffs, int n_coeffs, int realsize, int device, int *err)
+{
+    int dummy;
+    if (!err) err = &dummy;
+    *err = BFIR_OK;
+    const int blocklen = bfir_td_block_length(n_coeffs);
+    if (!coeffs || blocklen < 0 || (realsize != 4 && realsize != 8)) { *err = BFIR_ERR_ARG; return nullptr; }
+    int order = 1;
+    while ((1 << order) < 2 * blocklen) order++;
+    bfir_td_conv *t = new bfir_td_conv();
+    t->blocklen = blocklen;
+    t->plan = bfir_fft_plan_create(order, 0, 1, realsize, device, err);
+    if (!t->plan) { delete t; return nullptr; }
+    const size_t bytes = (size_t)2 * blocklen * realsize;
+    t->h_coeffs = bfir_aligned_malloc(bytes, 16);
+    if (!t->h_coeffs || hipMalloc(&t->d_coeffs, bytes) != hipSuccess) { *err = BFIR_ERR_HIP; bfir_td_destroy(t); return nullptr; }
+    const int rc = realsize == 4 ? td_new_t<float>(t, coeffs, n_coeffs) : td_new_t<double>(t, coeffs, n_coeffs);
+    if (rc != BFIR_OK) { *err = rc; bfir_td_destroy(t); return nullptr; }
+    return t;
+}
+
+template <typename T> static int td_convolve_t(bfir_td_conv *t, void *overlap_block)
+{
+    bfir_fft_plan *p = t->plan;
+    const size_t n = (size_t)p->n;
+    hipStream_t s = p->stream;
+    HIP_TRY(hipMemcpyAsync(p->d_a, overlap_block, n * sizeof(T), hipMemcpyHostToDevice, s));
+    r2hc_dev<T>(p);
+    hipLaunchKernelGGL(k_hc_mul_ordered<T>, dim3((unsigned)((n / 2 + 1 + 255) / 256)), dim3(256), 0, s, (T *)p->d_b,
+                       (const T *)t->d_coeffs, (long)n);
+    hc2r_dev<T>(p);
+    HIP_TRY(hipMemcpyAsync(overlap_block, p->d_a, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    return BFIR_OK;
+}
+
+// convolver_td_convolve: R2HC, ordered product with the filter's spectrum, HC2R, in place on the caller's
+// 2 * blocklen reals
+extern "C" int bfir_td_convolve(bfir_td_conv *t, void *overlap_block)
+{
+    if (!t || !overlap_block) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->plan->device));
+    return t->plan->realsize == 4 ? td_convolve_t<float>(t, overlap_block) : td_convolve_t<double>(t, overlap_block);
+}
+
+extern "C" int bfir_td_blocklen(const bfir_td_conv *t) { return t ? t->blocklen : 0; }
+extern "C" const void *bfir_td_coeffs(const bfir_td_conv *t) { return t ? t->h_coeffs : nullptr; }
 
 // ---------------------------------------------------------------------------
 // equalizer::render_f / render_d (brutefir/equalizer.cpp:211-299, 301-394)
@@ -300,7 +475,7 @@ template <typename T> __global__ void k_eq_fill(EqBands b, T *__restrict__ rbuf,
 extern "C" int bfir_equalizer_render(bfir_fft_plan *ifftplan, int band_count, const double *freq, const double *mag,
                                      const double *phase, void *ir_out)
 {
-    if (!ifftplan || !ifftplan->invert || band_count < 2 || band_count > EQ_MAX_BANDS || !freq || !mag || !phase || !ir_out)
+    if (!ifftplan || !ifftplan->invert || ifftplan->order < 5 || band_count < 2 || band_count > EQ_MAX_BANDS || !freq || !mag || !phase || !ir_out)
         return BFIR_ERR_ARG;
     bfir_fft_plan *p = ifftplan;
     HIP_TRY(hipSetDevice(p->device));

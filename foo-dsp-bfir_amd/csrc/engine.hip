@@ -60,6 +60,7 @@ extern "C" const char *bfir_strerror(int err)
     case BFIR_ERR_HIP: return "HIP runtime error";
     case BFIR_ERR_STATE: return "engine not initialised";
     case BFIR_ERR_UNSUPPORTED: return "unsupported format or size";
+    case BFIR_ERR_IO: return "file could not be opened";
     }
     return "unknown error";
 }

@@ -8,7 +8,9 @@
 // plumbing / parity path.  The measured path is bfir_engine_run*.
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -461,4 +463,36 @@ extern "C" int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs,
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (bad) bfir_logf("NaN or Inf value among coefficients.\n");
     return bad ? 0 : 1;
+}
+
+// convolver_debug_dump_cbuf (:604-651): every cbuf back to its coefficient list (OUTPUT reorder with scale 1,
+// HC2R in place; the taps are the UPPER half) as one "%.16e" line per value.  The reorder pair
+// grouped -> half-complex -> grouped of the stage kernels is a multiplication by 1.0 each way, so the
+// inverse kernel takes the cbuf as it is.  A file that cannot be opened is logged and skipped there
+// (a void method); here that is BFIR_ERR_IO as well.
+extern "C" int bfir_convolver_debug_dump_cbuf(bfir_convolver *c, const char *filename, void *const *cbufs, int n_cbufs)
+{
+    if (!c || !filename || !cbufs || n_cbufs < 0) return BFIR_ERR_ARG;
+    for (int n = 0; n < n_cbufs; n++) if (!cbufs[n]) return BFIR_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    FILE *stream = fopen(filename, "wt+");
+    if (!stream) {
+        bfir_logf("Could not open \"%s\" for writing: %s", filename, strerror(errno));
+        return BFIR_ERR_IO;
+    }
+    std::vector<char> vals((size_t)c->L * c->s);
+    int rc = BFIR_OK;
+    for (int n = 0; n < n_cbufs && rc == BFIR_OK; n++) {
+        InvArgs a;
+        a.src = c->d[0]; a.src_ch_stride = 0; a.dst = c->d[2]; a.dst_ch_stride = 0;
+        a.n_t = 1; a.n_ch = 1; a.in_scale = 1.0; a.full_output = 1;
+        if (hipMemcpyAsync(c->d[0], cbufs[n], cb(c), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = BFIR_ERR_HIP; break; }
+        launch_inv(c->plan, a, c->stream);
+        if (hipMemcpyAsync(vals.data(), (char *)c->d[2] + vals.size(), vals.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = BFIR_ERR_HIP; break; }
+        for (int i = 0; i < c->L; i++)
+            fprintf(stream, "%.16e\n", c->s == 4 ? (double)((const float *)vals.data())[i] : ((const double *)vals.data())[i]);
+    }
+    fclose(stream);
+    return rc;
 }

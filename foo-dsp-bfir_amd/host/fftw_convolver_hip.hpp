@@ -15,8 +15,9 @@
 //  * create_fft_plan returns a bfir_fft_plan* (an R2HC / HC2R plan of 2^order reals on the GPU), not an
 //    FFTW plan: a caller that executed it with fftw[f]_execute_r2r (equalizer.cpp:262, 357) calls
 //    bfir_fft_plan_execute(plan, in, out) instead.
-//  * convolver_debug_dump_cbuf (text-file dump) and the convolver_td_* family (used only
-//    by the dead `delay` class) are not provided.
+//  * td_conv_t (convolver_td_new) carries the reference's four fields plus the device-side handle
+//    `td`; td_conv_t.coeffs is a read-only host copy of the filter's spectrum.  The reference never
+//    frees a td_conv_t; convolver_td_free is the addition that does.
 #pragma once
 #include <stdexcept>
 
@@ -25,7 +26,14 @@
 #include "bfir_types.hpp"
 #include "dither_hip.hpp"
 
-struct _td_conv_t_;
+// fftw_convolver.hpp:18-26, plus the handle of the device-side object
+struct _td_conv_t_ {
+    void *fftplan;
+    void *ifftplan;
+    void *coeffs;
+    int blocklen;
+    bfir_td_conv *td;
+};
 typedef struct _td_conv_t_ td_conv_t;
 
 class fftw_convolver {
@@ -126,6 +134,42 @@ public:
     }
     // :569-602
     bool convolver_verify_cbuf(void *cbufs[], int n_cbufs) { return bfir_convolver_verify_cbuf(m_c, cbufs, n_cbufs) == 1; }
+
+    // :604-651: the coefficient lists behind cbufs[] as a text file, one "%.16e" line per tap
+    void convolver_debug_dump_cbuf(const char filename[], void *cbufs[], int n_cbufs)
+    {
+        m_last = bfir_convolver_debug_dump_cbuf(m_c, filename, cbufs, n_cbufs);
+    }
+
+    // :697-777: the one-block convolver of the (dead) delay class (delay.cpp:174, 196, 240-257)
+    int convolver_td_block_length(int n_coeffs) { return bfir_td_block_length(n_coeffs); }
+    td_conv_t *convolver_td_new(void *coeffs, int n_coeffs)
+    {
+        const int blocklen = convolver_td_block_length(n_coeffs);
+        if (blocklen == -1) return nullptr;
+        int err = 0, order = 1;
+        bfir_td_conv *td = bfir_td_new(coeffs, n_coeffs, m_realsize, m_device, &err);
+        m_last = err;
+        if (!td) return nullptr;
+        while ((1 << order) < blocklen) order++;
+        td_conv_t *tdc = new td_conv_t();
+        tdc->fftplan = create_fft_plan(order + 1, 0, 1);     // :726-727
+        tdc->ifftplan = create_fft_plan(order + 1, 1, 1);
+        tdc->coeffs = const_cast<void *>(bfir_td_coeffs(td));
+        tdc->blocklen = blocklen;
+        tdc->td = td;
+        return tdc;
+    }
+    void convolver_td_convolve(td_conv_t *tdc, void *overlap_block)
+    {
+        m_last = tdc ? bfir_td_convolve(tdc->td, overlap_block) : BFIR_ERR_ARG;
+    }
+    void convolver_td_free(td_conv_t *tdc)
+    {
+        if (!tdc) return;
+        bfir_td_destroy(tdc->td);
+        delete tdc;
+    }
 
     // :653-695: a plan per (order, invert, inplace), created on first use, owned by the convolver.
     // Returns a bfir_fft_plan* of 2^order reals: execute with bfir_fft_plan_execute(plan, in, out).

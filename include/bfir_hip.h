@@ -60,6 +60,7 @@ extern "C" {
 #define BFIR_ERR_HIP (-5)
 #define BFIR_ERR_STATE (-6)       /* engine not initialised (no coefficients) */
 #define BFIR_ERR_UNSUPPORTED (-7) /* sample format / size outside this build */
+#define BFIR_ERR_IO (-8)          /* a file could not be opened (convolver_debug_dump_cbuf) */
 
 /* bfoverflow_t, brutefir/global.h:96-102 (same layout) */
 typedef struct bfir_overflow {
@@ -246,6 +247,10 @@ int bfir_convolver_crossfade_inplace(bfir_convolver *c, void *input_cbuf, void *
                                      void *buffer_cbuf);
 /* convolver_verify_cbuf (:569-602): 1 = all finite, 0 = NaN/Inf found, < 0 = error */
 int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs, int n_cbufs);
+/* convolver_debug_dump_cbuf (:604-651): every cbuf converted back to its coefficient list and written as one
+ * "%.16e" line per tap (n_fft2 lines per cbuf).  BFIR_ERR_IO when the file cannot be opened (the reference
+ * logs and returns). */
+int bfir_convolver_debug_dump_cbuf(bfir_convolver *c, const char *filename, void *const *cbufs, int n_cbufs);
 /* ------------------------------------------------------------------ */
 /* FFT plans of any power-of-two size and the equalizer render          */
 /*                                                     */
@@ -253,8 +258,8 @@ int bfir_convolver_verify_cbuf(bfir_convolver *c, void *const *cbufs, int n_cbuf
 typedef struct bfir_fft_plan bfir_fft_plan;
 
 /* fftw_convolver::create_fft_plan(order, invert, inplace) (fftw_convolver.cpp:653-675):
- * FFTW_R2HC (invert 0) or FFTW_HC2R (invert 1) of 2^order reals, 5 <= order <= 25.
- * Sizes beyond one workgroup's LDS run as a four-step FFT. */
+ * FFTW_R2HC (invert 0) or FFTW_HC2R (invert 1) of 2^order reals, 1 <= order <= 25.
+ * Sizes beyond one workgroup's LDS run as a four-step FFT, sizes below 32 reals as direct sums. */
 bfir_fft_plan *bfir_fft_plan_create(int order, int invert, int inplace, int realsize, int device, int *err);
 void bfir_fft_plan_destroy(bfir_fft_plan *p);
 /* fftw[f]_execute_r2r(plan, in, out) on host buffers of 2^order reals; in == out allowed
@@ -266,6 +271,25 @@ int64_t bfir_fft_plan_length(const bfir_fft_plan *p);
  * ifftplan: an HC2R plan of `taps` reals. */
 int bfir_equalizer_render(bfir_fft_plan *ifftplan, int band_count, const double *freq, const double *mag,
                           const double *phase, void *ir_out);
+
+/* ------------------------------------------------------------------ */
+/* fftw_convolver::convolver_td_* (fftw_convolver.hpp:157-166): the     */
+/* one-block convolver of the reference's delay class (delay.cpp:174)   */
+/* ------------------------------------------------------------------ */
+typedef struct bfir_td_conv bfir_td_conv;
+/* convolver_td_block_length (fftw_convolver.cpp:697-706): n_coeffs rounded up to a power of two; -1 for
+ * n_coeffs < 2 (the reference's log2_roof(1) is -1 and it shifts by it: undefined there, refused here) */
+int bfir_td_block_length(int n_coeffs);
+/* convolver_td_new (:708-757): the spectrum of [blocklen zeros | taps | zeros], times 1 / (2 blocklen),
+ * resident on the device (td_conv_t; bfir_td_coeffs returns the host copy of td_conv_t.coeffs,
+ * 2 * blocklen reals in FFTW's half-complex order).  The reference never frees a td_conv_t. */
+bfir_td_conv *bfir_td_new(const void *coeffs, int n_coeffs, int realsize, int device, int *err);
+void bfir_td_destroy(bfir_td_conv *tdc);
+int bfir_td_blocklen(const bfir_td_conv *tdc);
+const void *bfir_td_coeffs(const bfir_td_conv *tdc);
+/* convolver_td_convolve (:759-777): R2HC, convolve_inplace_ordered (:819-856), HC2R in place on the
+ * caller's 2 * blocklen reals */
+int bfir_td_convolve(bfir_td_conv *tdc, void *overlap_block);
 
 void *bfir_aligned_malloc(size_t size, size_t alignment);
 void bfir_aligned_free(void *p);

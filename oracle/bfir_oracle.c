@@ -7,6 +7,7 @@
 #define _USE_MATH_DEFINES
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -19,6 +20,19 @@
 /* Sample format table: brutefir::setup_sample_format (brutefir/brutefir.cpp:435-538)
  * with the codes of brutefir/global.h:24-34.  `swap` is set for the *_BE formats,
  * i.e. the table assumes a little-endian host, like the reference's Win32 build. */
+/* log2_roof (brutefir/log2.h:33-51) and convolver_td_block_length (brutefir/fftw_convolver.cpp:697-706).
+ * log2_roof(1) is -1 there and the reference then shifts by it (undefined); here that case is -1. */
+int orc_td_block_length(int n_coeffs)
+{
+    uint32_t x = (uint32_t)n_coeffs;
+    int lg;
+    if (n_coeffs < 1) return -1;
+    for (lg = 31; (x & (1u << lg)) == 0 && lg > 0; lg--);
+    if (lg == 0 || (lg == 31 && (x & 0x7FFFFFFF) != 0)) return -1;
+    if ((x & ~(1u << lg)) != 0) lg++;
+    return 1 << lg;
+}
+
 int orc_fmt_bytes(int fmt)
 {
     static const int b[12] = {0, 1, 2, 2, 3, 3, 4, 4, 4, 4, 8, 8};
@@ -629,6 +643,29 @@ int orc_engine_run_blocks(orc_engine *e, const void *inbuf, void *outbuf, int n_
 }
 
 /* Independent checker: direct-form convolution, long double accumulation. */
+/* convolver_debug_dump_cbuf (brutefir/fftw_convolver.cpp:604-651): the text file.  Returns 0, or -1
+ * when the file cannot be opened (the reference logs and returns). */
+int orc_debug_dump_cbuf(const char *filename, int realsize, int n_fft, const void *const *cbufs, int n_cbufs)
+{
+    FILE *stream = fopen(filename, "wt+");
+    int n, i, n_fft2 = n_fft / 2;
+    void *vals;
+    if (!stream) return -1;
+    vals = malloc((size_t)n_fft2 * (size_t)realsize);
+    for (n = 0; n < n_cbufs; n++) {
+        if (realsize == 4) {
+            orc_debug_dump_values_f(n_fft, (const float *)cbufs[n], (float *)vals);
+            for (i = 0; i < n_fft2; i++) fprintf(stream, "%.16e\n", ((float *)vals)[i]);
+        } else {
+            orc_debug_dump_values_d(n_fft, (const double *)cbufs[n], (double *)vals);
+            for (i = 0; i < n_fft2; i++) fprintf(stream, "%.16e\n", ((double *)vals)[i]);
+        }
+    }
+    free(vals);
+    fclose(stream);
+    return 0;
+}
+
 void orc_direct_conv(const double *x, int n_x, const double *h, int n_h, double *y)
 {
     int n, k;

@@ -155,6 +155,23 @@ void orc_convolve_eval_d(int n_fft, const double *in, double *buffer, double *ou
 void orc_crossfade_inplace_f(int n_fft, float *input, float *crossfade, float *buffer);
 void orc_crossfade_inplace_d(int n_fft, double *input, double *crossfade, double *buffer);
 
+/* ---- the rest of the class's public methods (fftw_convolver.hpp:139-166) ---- */
+/* convolver_td_block_length (fftw_convolver.cpp:697-706); -1 for n_coeffs < 2 */
+int orc_td_block_length(int n_coeffs);
+/* convolve_inplace_ordered (:819-856): half-complex product of `size` reals, in place in b */
+void orc_convolve_inplace_ordered_f(int size, float *b, const float *c);
+void orc_convolve_inplace_ordered_d(int size, double *b, const double *c);
+/* convolver_td_new (:708-757): td_coeffs = 2 * blocklen reals; returns blocklen or -1 */
+int orc_td_new_f(const float *coeffs, int n_coeffs, float *td_coeffs);
+int orc_td_new_d(const double *coeffs, int n_coeffs, double *td_coeffs);
+/* convolver_td_convolve (:759-777): in place on 2 * blocklen reals */
+void orc_td_convolve_f(int blocklen, const float *td_coeffs, float *overlap_block);
+void orc_td_convolve_d(int blocklen, const double *td_coeffs, double *overlap_block);
+/* convolver_debug_dump_cbuf (:604-651): the n_fft2 values printed for one cbuf / the text file */
+void orc_debug_dump_values_f(int n_fft, const float *cbuf, float *vals);
+void orc_debug_dump_values_d(int n_fft, const double *cbuf, double *vals);
+int orc_debug_dump_cbuf(const char *filename, int realsize, int n_fft, const void *const *cbufs, int n_cbufs);
+
 /* ---- equalizer: brutefir/equalizer.cpp ---- */
 /* ctor + generate() up to the render call (:29-118): 33-entry tables; returns 33 or -1 */
 int orc_equalizer_bands(int sampling_rate, int n_bands, const double *freq, const double *mag,

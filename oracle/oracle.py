@@ -88,6 +88,13 @@ def lib():
             "orc_convolve_eval_f": (None, [ci, vp, vp, vp]), "orc_convolve_eval_d": (None, [ci, vp, vp, vp]),
             "orc_crossfade_inplace_f": (None, [ci, vp, vp, vp]),
             "orc_crossfade_inplace_d": (None, [ci, vp, vp, vp]),
+            "orc_td_block_length": (ci, [ci]),
+            "orc_convolve_inplace_ordered_f": (None, [ci, vp, vp]),
+            "orc_convolve_inplace_ordered_d": (None, [ci, vp, vp]),
+            "orc_td_new_f": (ci, [vp, ci, vp]), "orc_td_new_d": (ci, [vp, ci, vp]),
+            "orc_td_convolve_f": (None, [ci, vp, vp]), "orc_td_convolve_d": (None, [ci, vp, vp]),
+            "orc_debug_dump_values_f": (None, [ci, vp, vp]), "orc_debug_dump_values_d": (None, [ci, vp, vp]),
+            "orc_debug_dump_cbuf": (ci, [C.c_char_p, ci, ci, C.POINTER(vp), ci]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -243,6 +250,53 @@ def convolve_eval(x, buffer):
 def crossfade_inplace(inp, crossfade, buffer):
     """All three arrays are updated in place (as the reference's are)."""
     getattr(lib(), "orc_crossfade_inplace" + _suf(inp.dtype))(inp.size, _p(inp), _p(crossfade), _p(buffer))
+
+
+def td_block_length(n_coeffs):
+    """convolver_td_block_length; -1 for fewer than two taps."""
+    return lib().orc_td_block_length(int(n_coeffs))
+
+
+def convolve_inplace_ordered(b, c):
+    """Half-complex product (convolve_inplace_ordered); returns the product, b untouched."""
+    out = np.array(b, copy=True)
+    c = np.ascontiguousarray(c, dtype=out.dtype)
+    getattr(lib(), "orc_convolve_inplace_ordered" + _suf(out.dtype))(out.size, _p(out), _p(c))
+    return out
+
+
+def td_new(taps):
+    """convolver_td_new: (blocklen, 2 * blocklen half-complex coefficients)."""
+    taps = np.ascontiguousarray(taps)
+    blocklen = td_block_length(taps.size)
+    if blocklen < 0:
+        return -1, None
+    out = np.empty(2 * blocklen, dtype=taps.dtype)
+    got = getattr(lib(), "orc_td_new" + _suf(taps.dtype))(_p(taps), taps.size, _p(out))
+    assert got == blocklen
+    return blocklen, out
+
+
+def td_convolve(td_coeffs, overlap_block):
+    """convolver_td_convolve on a copy of overlap_block (2 * blocklen reals)."""
+    out = np.array(overlap_block, dtype=td_coeffs.dtype, copy=True)
+    getattr(lib(), "orc_td_convolve" + _suf(out.dtype))(out.size // 2, _p(td_coeffs), _p(out))
+    return out
+
+
+def debug_dump_values(cbuf):
+    """The n_fft2 values convolver_debug_dump_cbuf prints for one cbuf."""
+    cbuf = np.ascontiguousarray(cbuf)
+    out = np.empty(cbuf.size // 2, dtype=cbuf.dtype)
+    getattr(lib(), "orc_debug_dump_values" + _suf(cbuf.dtype))(cbuf.size, _p(cbuf), _p(out))
+    return out
+
+
+def debug_dump_cbuf(filename, cbufs):
+    """convolver_debug_dump_cbuf: writes the text file; 0 or -1 (cannot open)."""
+    cbufs = [np.ascontiguousarray(b) for b in cbufs]
+    arr = (C.c_void_p * len(cbufs))(*[b.ctypes.data for b in cbufs])
+    return lib().orc_debug_dump_cbuf(str(filename).encode(), cbufs[0].dtype.itemsize, cbufs[0].size, arr, len(cbufs))
 
 
 def equalizer_bands(sampling_rate, freq, mag, phase):

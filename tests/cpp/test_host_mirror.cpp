@@ -251,6 +251,52 @@ int main()
         CHECK(e < 1e-5, "plan round trip %g", e);
         conv.destroy_fft_plan(9, 0, 0);
     }
+    // the td convolver the way delay::subsample uses it (delay.cpp:150-180): blocks of `blocklen` samples,
+    // [rest | block] in, the first half out -- a filter whose only tap is 1 at `centre` delays the signal by
+    // `centre` samples -- and the text dump of a coefficient block (fftw_convolver.cpp:604-651)
+    {
+        const int n_taps = 31, centre = n_taps >> 1, frag = 512;
+        fftw_convolver conv(256, 8, nullptr);
+        const int bl = conv.convolver_td_block_length(n_taps);
+        CHECK(bl == 32 && conv.convolver_td_block_length(0) == -1 && conv.convolver_td_new(nullptr, 0) == nullptr, "td block length %d", bl);
+        std::vector<double> filt(n_taps, 0.0), sig(frag), out(frag), rest(bl, 0.0), cb(2 * bl);
+        filt[centre] = 1.0;
+        std::mt19937 rng(5); std::uniform_real_distribution<double> u(-1.0, 1.0);
+        for (auto &v : sig) v = u(rng);
+        td_conv_t *tdc = conv.convolver_td_new(filt.data(), n_taps);
+        CHECK(tdc && tdc->blocklen == bl && tdc->coeffs && tdc->fftplan && tdc->ifftplan, "convolver_td_new");
+        for (int i = 0; tdc && i < frag; i += bl) {
+            std::copy(rest.begin(), rest.end(), cb.begin());
+            std::copy(sig.begin() + i, sig.begin() + i + bl, cb.begin() + bl);
+            std::copy(cb.begin() + bl, cb.end(), rest.begin());
+            conv.convolver_td_convolve(tdc, cb.data());
+            CHECK(conv.last_status() == 0, "td_convolve: %s", bfir_strerror(conv.last_status()));
+            std::copy(cb.begin(), cb.begin() + bl, out.begin() + i);
+        }
+        // tap k sits at lag bl + k of the circular product, so the first half of [rest | block] comes back as the
+        // signal `centre` samples late: out[m] = sig[m - centre]
+        double worst = 0;
+        for (int m = 0; m < frag; m++) worst = std::max(worst, std::fabs(out[m] - (m < centre ? 0.0 : sig[m - centre])));
+        CHECK(worst < 1e-12, "td delay line off by %g", worst);
+        conv.convolver_td_free(tdc);
+        std::vector<double> taps(256);
+        for (auto &v : taps) v = u(rng);
+        void *blk = conv.convolver_coeffs2cbuf(taps.data(), 256, 1.0, nullptr);
+        const char *dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        std::string path = std::string(dir) + "/bfir_dump_test.txt";
+        void *blks[2] = {blk, blk};
+        conv.convolver_debug_dump_cbuf(path.c_str(), blks, 2);
+        CHECK(conv.last_status() == 0, "debug_dump_cbuf: %s", bfir_strerror(conv.last_status()));
+        FILE *fp = fopen(path.c_str(), "r");
+        int lines = 0; double v, werr = 0;
+        while (fp && fscanf(fp, "%lf", &v) == 1) { werr = std::max(werr, std::fabs(v - taps[lines % 256])); lines++; }
+        if (fp) fclose(fp);
+        CHECK(lines == 512 && werr < 1e-12, "dump: %d lines, error %g", lines, werr);
+        remove(path.c_str());
+        conv.convolver_debug_dump_cbuf("/nonexistent-dir/x.txt", blks, 2);
+        CHECK(conv.last_status() == BFIR_ERR_IO, "unwritable dump file must report BFIR_ERR_IO");
+        bfir_aligned_free(blk);
+    }
     printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -57,12 +57,20 @@ WORKLOADS = {
     # not BASELINE configs: the plug-in's own partition size (FILTER_LEN 1024)
     "plugin_8ch_131072tap_L1024_fp32": (8, 131072, 1024, 4),
     "plugin_8ch_65536tap_L1024_fp32": (8, 65536, 1024, 4),
+    "plugin_8ch_49152tap_L1024_fp32": (8, 49152, 1024, 4),
     "plugin_8ch_98304tap_L1024_fp32": (8, 98304, 1024, 4),
     "plugin_2ch_65536tap_L1024_fp64": (2, 65536, 1024, 8),    # the shipped REALSIZE 8 (common.h:17-19)
     "plugin_2ch_65536tap_L1024_fp32": (2, 65536, 1024, 4),
     # ... with the frames the plug-in really hands over: FLOAT_LE (32-bit) in and out around fp64 arithmetic
     # (foo_dsp_bfir.cpp:279-289); fifth field = frame sample bytes
     "plugin_2ch_65536tap_L1024_fp64_f32frames": (2, 65536, 1024, 8, 4),
+    # ... with longer impulses (the plug-in cuts whatever file it is given into 1024-sample partitions,
+    # foo_dsp_bfir.cpp:275-276): 48 / 96 / 128 / 192 / 256 partitions = 1.1 ... 5.9 s at 44.1 kHz
+    "plugin_2ch_49152tap_L1024_fp64_f32frames": (2, 49152, 1024, 8, 4),
+    "plugin_2ch_98304tap_L1024_fp64_f32frames": (2, 98304, 1024, 8, 4),
+    "plugin_2ch_131072tap_L1024_fp64_f32frames": (2, 131072, 1024, 8, 4),
+    "plugin_2ch_196608tap_L1024_fp64_f32frames": (2, 196608, 1024, 8, 4),
+    "plugin_2ch_262144tap_L1024_fp64_f32frames": (2, 262144, 1024, 8, 4),
 }
 
 

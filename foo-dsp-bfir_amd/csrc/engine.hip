@@ -302,13 +302,13 @@ extern "C" bfir_engine *bfir_engine_create_batch(int n_engines, int filter_lengt
         // fp64 engines whose transforms the run kernels take keep their spectra -- delay line, filter partitions, products --
         // as (re, im) PAIRS like the fp32 engines, not in the reference's groups of four: one 16-byte access per bin in the
         // MAC instead of two of 8, the forward kernel's spectrum straight from registers (no LDS staging), conflict-free reads
-        // in the inverse.  Only where every kernel on the engine's way reads pairs: direct mode, the systolic MAC (up to 128
+        // in the inverse.  Only where every kernel on the engine's way reads pairs: direct mode, the systolic MAC (up to 256
         // partitions) -- so the switches that pick other kernels keep the groups (all read HERE, at creation, for such engines).
         // BFIR_F64_PAIRS=0: off (A/B).  Same arithmetic either way: the same bits.
         {
             const char *fp = getenv("BFIR_F64_PAIRS"), *ms = getenv("BFIR_MAC_SYS"), *mv = getenv("BFIR_MAC_VARIANT");
             const bool other_mac = (ms && atoi(ms) == 0) || getenv("BFIR_MAC64_VARIANT") || getenv("BFIR_MAC_BATCHED") || (mv && atoi(mv) != 0);
-            if (realsize == 8 && e->direct && pairs64_supported(filter_length, realsize) && filter_blocks <= 128 && !other_mac &&
+            if (realsize == 8 && e->direct && pairs64_supported(filter_length, realsize) && filter_blocks <= BFIR_MAC_SYS_MAX_B && !other_mac &&
                 !(fp && atoi(fp) == 0))
                 e->ilv = true;
         }

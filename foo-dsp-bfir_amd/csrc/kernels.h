@@ -157,6 +157,7 @@ inline int bfir_alias_env(const char *name) { const char *e = getenv(name); retu
 #endif
 void launch_mac(const MacArgs &a, hipStream_t s);
 // mac_sys.hip: the forward-walking two-lanes-per-bin form of the fp32 pair-layout MAC (B <= 32)
+constexpr int BFIR_MAC_SYS_MAX_B = 256;   // partitions the systolic MAC takes (sixteen stages of sixteen)
 bool mac_sys_supported(const MacArgs &a);
 void launch_mac_sys(const MacArgs &a, hipStream_t s);
 

@@ -2151,7 +2151,7 @@ void launch_mac(const MacArgs &a, hipStream_t s)
     if (a.n_t <= 0 || a.n_ch <= 0) return;
     const int tt = a.n_t;
     if (tt <= BFIR_MAC_SMALL_MAX && !getenv("BFIR_NO_MAC_SMALL")) { launch_mac_small(a, s); return; }   // env: A/B and tests
-    {   // The forward-walking systolic kernel (mac_sys.hip: up to 128 partitions; fp32 on the pairs layout, fp64 on either):
+    {   // The forward-walking systolic kernel (mac_sys.hip: up to 256 partitions; fp32 on the pairs layout, fp64 on either):
         // the default for fp64 (cfg5 +14 %, its MAC -27 % against the LDS-tiled kernel) and for fp32 with 33 to
         // 64 partitions (+1..5 % against k_mac_lds; with eight lanes per bin, 65 to 128 partitions, it is 10 % SLOWER:
         // 44.7 against 49.6 Gsamples/s at 8 channels x 128 partitions of 1024); with up to 32 partitions k_mac_stream stays

@@ -26,7 +26,7 @@
 //   * the walk is forward: y[t] leaves S - 1 slots after x[t] has arrived, a run of R outputs costs R + S - 1 slots and
 //     S (PL + 1) window loads of history: short runs are cheap;
 //   * the same kernel serves fp32 (pairs layout) and fp64 (pairs, or the reference's grouped layout: re and im 32 bytes
-//     apart), S PL >= B partitions: up to 128.
+//     apart), S PL >= B partitions: up to 256 (sixteen stages: a whole DPP row per bin).
 // Bin 0 (DC | Nyquist: two independent real sums) is left to the first workgroups of the grid, as in k_mac_stream.
 #include "kernels.h"
 
@@ -342,31 +342,40 @@ template <typename T, bool ILV, int S, int PL, int D> static void launch_sys(con
 }
 
 // fp32 on the pairs layout (whole columns of 256 / S bins: N / 2 >= 128), fp64 on the grouped layout (N / 2 >= 64 bins,
-// i.e. the engines with N >= 512 either way); S PL >= B: up to 128 partitions
+// i.e. the engines with N >= 512 either way); S PL >= B: up to BFIR_MAC_SYS_MAX_B = 256 partitions
 bool mac_sys_supported(const MacArgs &a)
 {
     if (a.N < 512) return false;
     // 32-bit byte offsets into one channel's delay line, and 2 GiB as the "nowhere" offset of the lanes that do not store
     const unsigned long long spec = (unsigned long long)a.N * (unsigned)a.realsize;
     if (spec * (unsigned)a.ring >= (1ull << 32) || spec * (unsigned)a.n_t > (1ull << 31)) return false;
-    if (a.realsize == 4) return a.interleaved && a.B <= 128;
-    return a.B <= 128;                                       // fp64: either layout
+    if (a.realsize == 4) return a.interleaved && a.B <= BFIR_MAC_SYS_MAX_B;
+    return a.B <= BFIR_MAC_SYS_MAX_B;                        // fp64: either layout
 }
 
+// Stages x partitions per stage: the smallest S PL >= B the build holds.  Partitions beyond B are zeros the lanes multiply
+// all the same (the stages of a bin are lanes of one wave), so the steps are kept at a quarter: PL = 12 between the powers of
+// two (the plug-in cuts whatever impulse file it is given into 1024-sample partitions, foo_dsp_bfir.cpp:275-276: any count
+// occurs).  fp64: prefetch depth 6 with 16 partitions per stage (160 registers, three waves per SIMD; measured best, cfg5
+// 39.7 against 39.2 with 4 and 39.4 with 8, the plug-in's shape 43.3 / 40.1 / 43.7, profiles/r03_fp64.txt; BFIR_SYS_D
+// overrides at 33 ... 64 partitions), 4 with 12 (128 registers: four waves).
 template <bool ILV> static void launch_sys_f64(const MacArgs &a, hipStream_t s)
 {
     if (a.B <= 16) launch_sys<double, ILV, 2, 8, 4>(a, s);
+    else if (a.B <= 24) launch_sys<double, ILV, 2, 12, 4>(a, s);
     else if (a.B <= 32) launch_sys<double, ILV, 2, 16, 4>(a, s);
-    else if (a.B > 64) launch_sys<double, ILV, 8, 16, 6>(a, s);   // eight stages: 65 ... 128 partitions
-    else {
-        // prefetch depth in slots: 6 (160 registers, three waves per SIMD) measured best, cfg5 39.7 against 39.2 (4)
-        // and 39.4 (8), the plug-in's shape 43.3 / 40.1 / 43.7 (profiles/r03_fp64.txt); BFIR_SYS_D overrides
+    else if (a.B <= 48) launch_sys<double, ILV, 4, 12, 4>(a, s);
+    else if (a.B <= 64) {
         const char *de = getenv("BFIR_SYS_D");
         const int d = de ? atoi(de) : 6;
         if (d >= 8) launch_sys<double, ILV, 4, 16, 8>(a, s);
         else if (d == 6) launch_sys<double, ILV, 4, 16, 6>(a, s);
         else launch_sys<double, ILV, 4, 16, 4>(a, s);
     }
+    else if (a.B <= 96) launch_sys<double, ILV, 8, 12, 4>(a, s);
+    else if (a.B <= 128) launch_sys<double, ILV, 8, 16, 6>(a, s);    // eight stages: 65 ... 128 partitions
+    else if (a.B <= 192) launch_sys<double, ILV, 16, 12, 4>(a, s);   // sixteen stages, one DPP row per bin: 129 ... 256 partitions
+    else launch_sys<double, ILV, 16, 16, 6>(a, s);                   // (1024-sample blocks, an impulse of up to 5.9 s at 44.1 kHz)
 }
 
 void launch_mac_sys(const MacArgs &a, hipStream_t s)
@@ -375,8 +384,10 @@ void launch_mac_sys(const MacArgs &a, hipStream_t s)
         if (a.B <= 8) launch_sys<float, true, 2, 4, 4>(a, s);
         else if (a.B <= 16) launch_sys<float, true, 2, 8, 4>(a, s);
         else if (a.B <= 32) launch_sys<float, true, 2, 16, 4>(a, s);
+        else if (a.B <= 48) launch_sys<float, true, 4, 12, 4>(a, s);
         else if (a.B <= 64) launch_sys<float, true, 4, 16, 4>(a, s);
-        else launch_sys<float, true, 8, 16, 4>(a, s);
+        else if (a.B <= 128) launch_sys<float, true, 8, 16, 4>(a, s);
+        else launch_sys<float, true, 16, 16, 4>(a, s);
     } else if (a.interleaved) launch_sys_f64<true>(a, s);
     else launch_sys_f64<false>(a, s);
 }

@@ -90,7 +90,8 @@ def test_register_budgets_of_the_persistent_kernels():
                                 (r"k_(fwd|inv)_(pair|tp)_ps", 3, 20),
                                 (r"k_mac_sysIfLb1ELi2ELi16ELi4E", 6, 1), (r"k_mac_sysIfLb1ELi4ELi16ELi4E", 6, 1),
                                 (r"k_mac_sysIdLb[01]ELi4ELi16ELi6E", 3, 2), (r"k_mac_sysIdLb[01]ELi2ELi16ELi4E", 3, 2),   # fp64: both spectrum layouts
-                                (r"k_mac_sysIdLb[01]ELi8ELi16ELi6E", 3, 2)):
+                                (r"k_mac_sysIdLb[01]ELi8ELi16ELi6E", 3, 2), (r"k_mac_sysIdLb[01]ELi16ELi16ELi6E", 3, 2),
+                                (r"k_mac_sysIdLb[01]ELi(2|4|8|16)ELi12ELi4E", 4, 8), (r"k_mac_sysIfLb1ELi4ELi12ELi4E", 6, 1)):   # twelve partitions per stage
         ks = pick(pattern)
         assert n is None or len(ks) == n, (pattern, sorted(ks))
         for name, r in ks.items():

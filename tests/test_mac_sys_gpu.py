@@ -5,7 +5,7 @@ Every output is ONE fused multiply-add chain over the partitions in the referenc
 k_mac_lds on the pair layout, the fp64 LDS kernel) -- so it must agree with them BIT FOR BIT on every block, whatever
 the launch geometry: run lengths that are no multiple of the slot group, runs shorter than the filter, the ring wrap
 inside a run (the stages pass it PL + 1 slots apart), partition counts below S PL (zero partitions), ragged last
-partitions, several engines, call-to-call continuation, two / four / eight lanes per bin, fp32 (pairs layout) and fp64
+partitions, several engines, call-to-call continuation, two / four / eight / sixteen lanes per bin, fp32 (pairs layout) and fp64
 (the reference's grouped layout).  The default kernels are checked against the oracle throughout the suite; two shapes
 here go to the oracle directly."""
 import numpy as np
@@ -38,6 +38,18 @@ SHAPES = [
     ("d_B9_S2_PL8", 256, 9, 2, 1, 300, [300, 300], 300, {"BFIR_MAC_RANGE": "11"}),
     ("d_B100_S8", 512, 100, 2, 1, 260, [260, 33, 260], 260, {}),
     ("d_B128_S8_wrap", 1024, 128, 1, 2, 300, [300, 300], 150, {"BFIR_MAC_RANGE": "45"}),
+    # sixteen lanes per bin (a whole DPP row): 129 ... 256 partitions
+    ("d_B129_S16", 1024, 129, 2, 1, 300, [300, 41, 300], 300, {}),
+    ("d_B256_S16_wrap", 512, 256, 1, 2, 400, [400, 400], 200, {"BFIR_MAC_RANGE": "45"}),
+    ("d_B200_S16_runs_shorter_than_filter", 1024, 200, 3, 1, 260, [260, 260, 3], 260, {"BFIR_MAC_RANGE": "19"}),
+    ("B160_S16", 1024, 160, 2, 1, 300, [300, 300], 300, {}),
+    # twelve partitions per stage: the quarter steps between the powers of two (24 / 48 / 96 / 192)
+    ("d_B23_S2_PL12", 1024, 23, 2, 1, 300, [300, 300], 150, {"BFIR_MAC_RANGE": "29"}),
+    ("d_B44_S4_PL12", 1024, 44, 2, 1, 300, [300, 55, 300], 300, {}),
+    ("d_B90_S8_PL12_wrap", 512, 90, 3, 1, 300, [300, 300], 100, {"BFIR_MAC_RANGE": "31"}),
+    ("d_B188_S16_PL12", 1024, 188, 2, 1, 300, [300, 300, 2], 300, {}),
+    ("d_B192_S16_PL12_runs_shorter_than_filter", 512, 192, 1, 2, 260, [260, 260], 260, {"BFIR_MAC_RANGE": "17"}),
+    ("B47_S4_PL12", 1024, 47, 2, 1, 400, [400, 77, 400], 200, {}),
 ]
 
 

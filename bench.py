@@ -54,6 +54,8 @@ WORKLOADS = {
     "cfg2_2ch_65536tap_L8192_fp32": (2, 65536, 8192, 4),
     "cfg5_2ch_262144tap_L4096_fp64": (2, 262144, 4096, 8),
     "cfg4_stereo_65536tap_L4096_fp32": (2, 65536, 4096, 4),   # per stream; use with --streams
+    # the headline's shape with 24 partitions (a count between two of k_mac_stream's register batches)
+    "hl_8ch_98304tap_L4096_fp32": (8, 98304, 4096, 4),
     # not BASELINE configs: the plug-in's own partition size (FILTER_LEN 1024)
     "plugin_8ch_131072tap_L1024_fp32": (8, 131072, 1024, 4),
     "plugin_8ch_65536tap_L1024_fp32": (8, 65536, 1024, 4),

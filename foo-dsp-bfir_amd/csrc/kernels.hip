@@ -2156,9 +2156,11 @@ void launch_mac(const MacArgs &a, hipStream_t s)
         // 64 partitions (+1..5 % against k_mac_lds; with eight lanes per bin, 65 to 128 partitions, it is 10 % SLOWER:
         // 44.7 against 49.6 Gsamples/s at 8 channels x 128 partitions of 1024); with up to 32 partitions k_mac_stream stays
         // ahead (0.49 against 0.59 ms per 4096 headline blocks: two lanes per bin double the vector-memory instructions
-        // per FMA, profiles/r03_mac_sys.txt).  BFIR_MAC_SYS=1 / 0 forces / forbids it; read per launch (tests switch it).
+        // per FMA, profiles/r03_mac_sys.txt) -- except at 17 to 24 partitions, where it pays for a register batch of 32 and two
+        // stages of twelve do not (MAC 0.49 -> 0.45 ms, 116.2 -> 118.3 Gsamples/s at the headline's shape with 24 partitions).
+        // BFIR_MAC_SYS=1 / 0 forces / forbids it; read per launch (tests switch it).
         const char *ms = getenv("BFIR_MAC_SYS");
-        const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || (a.B > 32 && a.B <= 64)) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
+        const bool want = ms ? atoi(ms) != 0 : (a.realsize == 8 || (a.B > 32 && a.B <= 64) || (a.B > 16 && a.B <= 24)) && !getenv("BFIR_MAC64_VARIANT") && mac_variant() == 0;
         if (want && mac_sys_supported(a) && !getenv("BFIR_MAC_BATCHED")) { launch_mac_sys(a, s); return; }
         // an fp64 engine on (re, im) pairs (engine.hip picks that layout only where this kernel serves it, and looks at the
         // same switches when it does): no other fp64 MAC kernel reads pairs

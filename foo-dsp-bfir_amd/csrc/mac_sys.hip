@@ -383,6 +383,7 @@ void launch_mac_sys(const MacArgs &a, hipStream_t s)
     if (a.realsize == 4) {
         if (a.B <= 8) launch_sys<float, true, 2, 4, 4>(a, s);
         else if (a.B <= 16) launch_sys<float, true, 2, 8, 4>(a, s);
+        else if (a.B <= 24) launch_sys<float, true, 2, 12, 4>(a, s);
         else if (a.B <= 32) launch_sys<float, true, 2, 16, 4>(a, s);
         else if (a.B <= 48) launch_sys<float, true, 4, 12, 4>(a, s);
         else if (a.B <= 64) launch_sys<float, true, 4, 16, 4>(a, s);

@@ -75,7 +75,11 @@ run plugin_fp64_f32frames_6ch --workload plugin_2ch_65536tap_L1024_fp64_f32frame
 for C in 5 3 1; do run plugin_fp64_f32frames_${C}ch --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels $C; done
 BFIR_RUN64=0 run plugin_fp64_f32frames_one_transform_kernels --workload plugin_2ch_65536tap_L1024_fp64_f32frames
 BFIR_RUN64=0 run plugin_fp64_f32frames_5ch_staging_r02 --workload plugin_2ch_65536tap_L1024_fp64_f32frames --channels 5
+for T in 49152 98304 131072 196608 262144; do run plugin_fp64_f32frames_${T}taps --workload plugin_2ch_${T}tap_L1024_fp64_f32frames; done   # 48 ... 256 partitions
+BFIR_MAC_SYS=0 run plugin_fp64_f32frames_262144taps_lds_mac --workload plugin_2ch_262144tap_L1024_fp64_f32frames
 run plugin_fp32 --workload plugin_2ch_65536tap_L1024_fp32
+run plugin_8ch_B48 --workload plugin_8ch_49152tap_L1024_fp32
+run hl_8ch_24_partitions --workload hl_8ch_98304tap_L4096_fp32 --blocks 65536
 run plugin_8ch_B64 --workload plugin_8ch_65536tap_L1024_fp32
 run plugin_8ch_B128 --workload plugin_8ch_131072tap_L1024_fp32
 BFIR_MAC_SYS=0 run plugin_8ch_B128_r02_mac --workload plugin_8ch_131072tap_L1024_fp32

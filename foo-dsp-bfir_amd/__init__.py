@@ -7,12 +7,12 @@ from ._lib import (ERR_ARG, ERR_COEFF, ERR_HIP, ERR_IO, ERR_NO_DEVICE, ERR_NONFI
                    ERR_UNSUPPORTED, BfirError, BufferFormat, Overflow, SampleFormat, MIXMODE_INPUT, MIXMODE_OUTPUT,
                    SAMPLE_FORMAT_FLOAT64_LE, SAMPLE_FORMAT_FLOAT_LE, load, library_path)
 from .convolver import Dither, FftwConvolver, TdConv
-from .engine import Brutefir
+from .engine import Brutefir, pinned_frames
 from .equalizer import Equalizer, FftPlan
 
 build = _build.build
 
-__all__ = ["Brutefir", "FftwConvolver", "TdConv", "Dither", "Equalizer", "FftPlan", "BfirError", "BufferFormat", "Overflow", "SampleFormat",
+__all__ = ["Brutefir", "pinned_frames", "FftwConvolver", "TdConv", "Dither", "Equalizer", "FftPlan", "BfirError", "BufferFormat", "Overflow", "SampleFormat",
            "MIXMODE_INPUT", "MIXMODE_OUTPUT", "SAMPLE_FORMAT_FLOAT_LE", "SAMPLE_FORMAT_FLOAT64_LE",
            "build", "load", "library_path", "ERR_ARG", "ERR_COEFF", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_NONFINITE", "ERR_STATE", "ERR_UNSUPPORTED", "ERR_IO"]

@@ -103,6 +103,8 @@ SIGNATURES = {
     "bfir_fft_plan_execute": (_ci, [_vp, _vp, _vp]),
     "bfir_fft_plan_length": (_cl, [_vp]),
     "bfir_equalizer_render": (_ci, [_vp, _ci, C.POINTER(_cd), C.POINTER(_cd), C.POINTER(_cd), _vp]),
+    "bfir_pinned_malloc": (_vp, [C.c_size_t]),
+    "bfir_pinned_free": (None, [_vp]),
     "bfir_aligned_malloc": (_vp, [C.c_size_t, C.c_size_t]),
     "bfir_aligned_free": (None, [_vp]),
 }

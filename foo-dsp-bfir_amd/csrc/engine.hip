@@ -920,6 +920,32 @@ static void copy_host(void *dst, const void *src, size_t n)
     for (auto &t : th) t.join();
 }
 
+// Is [p, p + n) page-locked host memory the copy engines can reach directly (bfir_pinned_malloc, or the caller's own
+// hipHostMalloc / hipHostRegister)?  Then the staging memcpy -- one pass of a few host cores over every byte, the slowest leg
+// of the host-pointer path -- is skipped for that buffer.
+static bool is_pinned_host(const void *p, size_t n)
+{
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable: not known to the runtime
+    if (a0.type != hipMemoryTypeHost) return false;
+    if (n <= 1) return true;
+    if (hipPointerGetAttributes(&a1, (const char *)p + n - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a1.type == hipMemoryTypeHost;
+}
+
+extern "C" void *bfir_pinned_malloc(size_t size)
+{
+    void *p = nullptr;
+    if (bfir_device_count() <= 0) return nullptr;
+    if (hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void bfir_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 // Host-path chunk: the link, not the GPU, bounds this path, so the pinned staging buffers stay small.
 static int host_chunk(const bfir_engine *e) { return std::min(e->chunk, 512); }
 
@@ -1024,9 +1050,14 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
     const size_t eng_in = (size_t)n_blocks * e->L * fin, eng_out = (size_t)n_blocks * e->L * fout;
     const int hc = host_chunk(e);
     const int nchunks = (n_blocks + hc - 1) / hc;
+    // page-locked caller buffers go straight to / from the copy engines (no staging memcpy); BFIR_NO_PINNED_DIRECT=1: A/B, tests
+    const bool direct_ok = !getenv("BFIR_NO_PINNED_DIRECT");
+    const bool in_direct = direct_ok && is_pinned_host(inbuf, eng_in * e->n_eng);
+    const bool out_direct = direct_ok && is_pinned_host(outbuf, eng_out * e->n_eng);
     auto copy_out = [&](int k) -> int {
         const int b = k & 1, c0 = k * hc, tc = std::min(hc, n_blocks - c0);
         HIP_TRY(hipEventSynchronize(e->ev_d2h[b]));
+        if (out_direct) return BFIR_OK;
         const size_t per = (size_t)tc * e->L * fout;
         for (int g = 0; g < e->n_eng; g++)
             copy_host((char *)outbuf + g * eng_out + (size_t)c0 * e->L * fout, (char *)e->pin_out[b] + g * per, per);
@@ -1036,16 +1067,27 @@ extern "C" int bfir_engine_run(bfir_engine *e, const void *inbuf, void *outbuf, 
         const int b = k & 1, c0 = k * hc, tc = std::min(hc, n_blocks - c0);
         if (k >= 2) { rc = copy_out(k - 2); if (rc != BFIR_OK) return rc; }
         const size_t per_in = (size_t)tc * e->L * fin, per_out = (size_t)tc * e->L * fout;
-        for (int g = 0; g < e->n_eng; g++)
-            copy_host((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
-        HIP_TRY(hipMemcpyAsync(e->dev_in[b], e->pin_in[b], per_in * e->n_eng, hipMemcpyHostToDevice, e->s_in));
+        if (in_direct) {
+            for (int g = 0; g < e->n_eng; g++)
+                HIP_TRY(hipMemcpyAsync((char *)e->dev_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin,
+                                       per_in, hipMemcpyHostToDevice, e->s_in));
+        } else {
+            for (int g = 0; g < e->n_eng; g++)
+                copy_host((char *)e->pin_in[b] + g * per_in, (const char *)inbuf + g * eng_in + (size_t)c0 * e->L * fin, per_in);
+            HIP_TRY(hipMemcpyAsync(e->dev_in[b], e->pin_in[b], per_in * e->n_eng, hipMemcpyHostToDevice, e->s_in));
+        }
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->s_in));
         rc = run_chunk(e, e->dev_in[b], (long)per_in, e->dev_out[b], (long)per_out, 0, tc, c0, e->stream,
                        e->ev_h2d[b]);
         if (rc != BFIR_OK) return rc;
         HIP_TRY(hipEventRecord(e->ev_comp[b], e->stream));
         HIP_TRY(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
-        HIP_TRY(hipMemcpyAsync(e->pin_out[b], e->dev_out[b], per_out * e->n_eng, hipMemcpyDeviceToHost, e->s_out));
+        if (out_direct) {
+            for (int g = 0; g < e->n_eng; g++)
+                HIP_TRY(hipMemcpyAsync((char *)outbuf + g * eng_out + (size_t)c0 * e->L * fout, (char *)e->dev_out[b] + g * per_out,
+                                       per_out, hipMemcpyDeviceToHost, e->s_out));
+        } else
+            HIP_TRY(hipMemcpyAsync(e->pin_out[b], e->dev_out[b], per_out * e->n_eng, hipMemcpyDeviceToHost, e->s_out));
         HIP_TRY(hipEventRecord(e->ev_d2h[b], e->s_out));
         // the next H2D into dev_in[b] must not overtake this chunk's kernels
         HIP_TRY(hipStreamWaitEvent(e->s_in, e->ev_comp[b], 0));

@@ -29,6 +29,25 @@ def raw_frames(fmt, shape_frames_channels):
     return np.zeros(shape + (3,), np.uint8) if d is None else np.zeros(shape, d)
 
 
+def pinned_frames(fmt, shape_frames_channels):
+    """raw_frames in page-locked host memory (bfir_pinned_malloc): `Brutefir.run` on such arrays skips the staging copies.
+    The array keeps its allocation alive; it is released when the array is collected."""
+    import weakref
+    d = _FMT_DTYPES[fmt]
+    shape = tuple(shape_frames_channels) + ((3,) if d is None else ())
+    dt = np.dtype(np.uint8) if d is None else d
+    n = int(np.prod(shape)) * dt.itemsize
+    lib = _lib.load()
+    p = lib.bfir_pinned_malloc(n)
+    if not p:
+        raise BfirError(_lib.ERR_HIP, "bfir_pinned_malloc")
+    buf = (C.c_char * n).from_address(p)
+    a = np.frombuffer(buf, dtype=dt).reshape(shape)
+    weakref.finalize(buf, lib.bfir_pinned_free, p)
+    a[...] = 0
+    return a
+
+
 class Brutefir:
     """brutefir(filter_length, filter_blocks, realsize, channels, in_format,
     out_format, sampling_rate, apply_dither)  -- brutefir/brutefir.hpp:18-25.

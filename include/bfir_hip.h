@@ -291,6 +291,13 @@ const void *bfir_td_coeffs(const bfir_td_conv *tdc);
  * caller's 2 * blocklen reals */
 int bfir_td_convolve(bfir_td_conv *tdc, void *overlap_block);
 
+/* Page-locked host memory for frame buffers handed to bfir_engine_run: the copy engines read and write it directly, so the
+ * staging memcpy through the engine's own pinned buffers is skipped (the reference's callers allocate their frame buffers
+ * with _aligned_realloc, foo_dsp_bfir.cpp:291-293; any hipHostMalloc / hipHostRegister'ed buffer is recognised the same way).
+ * NULL without a GPU. */
+void *bfir_pinned_malloc(size_t size);
+void bfir_pinned_free(void *p);
+
 void *bfir_aligned_malloc(size_t size, size_t alignment);
 void bfir_aligned_free(void *p);
 

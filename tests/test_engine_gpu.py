@@ -512,3 +512,36 @@ def test_fp64_mac_variants_give_identical_bits(orc, bfir, variant):
     assert np.array_equal(outs[0], outs[1])
     ref = orc.Engine(L, B, 8, C); ref.set_coeff(h)
     assert rel_err(outs[0], ref.run(x)[1]) <= TOL[8]
+
+
+@pytest.mark.parametrize("n_eng", [1, 3])
+def test_pinned_frame_buffers_skip_the_staging_copies_with_the_same_bits(orc, bfir, n_eng):
+    """bfir_engine_run on page-locked caller buffers (bfir_pinned_malloc) DMAs them directly; pageable buffers go through the
+    engine's staging buffers.  Same kernels either way: the same bits -- several host chunks (512 blocks each), a ragged
+    last chunk, a batch of engines (one transfer per engine and chunk), and each buffer pinned on its own."""
+    s, L, B, C, nb = 4, 256, 3, 2, 1100
+    rng = np.random.default_rng(23)
+    hs = [orc.synth_ir(rng, C, B * L - 5, np.float32) for _ in range(n_eng)]
+    x = np.stack([orc.synth_audio(rng, nb * L, C, np.float32) for _ in range(n_eng)])
+    shape = x.shape if n_eng > 1 else x.shape[1:]
+
+    def engine():
+        e = bfir.Brutefir(L, B, s, C, n_engines=n_eng)
+        for g in range(n_eng):
+            assert e.set_coeff(hs[g], engine_index=g) == 0
+        return e
+
+    rc, want = engine().run(x.reshape(shape))
+    assert rc == 0
+    ref = orc.Engine(L, B, s, C); ref.set_coeff(hs[0])
+    assert rel_err(want.reshape(x.shape)[0][:40 * L], ref.run(x[0][:40 * L])[1]) <= TOL[s]
+    for pin_in, pin_out in ((True, True), (True, False), (False, True)):
+        xin = bfir.pinned_frames(bfir.SAMPLE_FORMAT_FLOAT_LE, shape) if pin_in else np.empty(shape, np.float32)
+        xin[...] = x.reshape(shape)
+        yout = bfir.pinned_frames(bfir.SAMPLE_FORMAT_FLOAT_LE, shape) if pin_out else np.empty(shape, np.float32)
+        rc, got = engine().run(xin, yout)
+        assert rc == 0 and got is yout
+        assert np.array_equal(got, want), (pin_in, pin_out)
+    with env_override(BFIR_NO_PINNED_DIRECT="1"):       # the switch puts pinned buffers back on the staging path
+        xin = bfir.pinned_frames(bfir.SAMPLE_FORMAT_FLOAT_LE, shape); xin[...] = x.reshape(shape)
+        assert np.array_equal(engine().run(xin)[1], want)

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void k_stage_out_dither(StageOutArgs a, int byt
     const int L = a.L, n_blocks = (int)(a.n_frames / L);
     for (int t = 0; t < n_blocks; t++) {
         // brutefir.cpp:316-321: sample 0 of the block decides run()'s verdict
-        if (!isfinite((double)src[(long)t * L])) atomicMin(a.bad_block, a.block_base + t);
+        if (!isfinite((double)src[(long)t * L])) flag_bad(a, t);
         // dither_preloop_real2int_hp_tpdf (dither.cpp:127-139).  The reference copies the last byte
         // used into table[0] on a wrap; only the wrapping channel ever reads it (as tab[-1] of this
         // very block), so the shared table stays read-only here and the byte is taken where it lies.

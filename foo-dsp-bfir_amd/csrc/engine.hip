@@ -148,7 +148,8 @@ struct bfir_engine {
     // on one stream, no events, kernels read and write the pinned staging buffers across the host link
     bool inline_launch = false;            // set around run_chunk by run_small()
     bool async_pending = false;            // run_device queued work that nobody has waited for yet
-    int *h_bad = nullptr;                  // pinned copy of d_bad
+    int *h_bad = nullptr;                  // pinned: one flag per block of a latency-path call (flag_bad, kernels.h)
+    int *bad_host_cur = nullptr;           // ... what the kernels of the chunk being launched are given (null outside run_small)
     bool serial = false;                   // BFIR_PIPE=1: everything on the caller's stream (kernel timing runs)
     // host-pointer path: pinned + device staging, double buffered
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
@@ -654,7 +655,7 @@ static int run_chunk_pair(bfir_engine *e, const void *d_in, long in_stride, void
         a.raw = (float *)d_out; a.eng_stride = out_stride / 4; a.frame_off = frame_off;
         a.C = e->C; a.n_eng = e->n_eng; a.n_t = tc;
         a.scale = (float)e->out_scale; a.max = (float)e->of_max;
-        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base; a.bad_host = e->bad_host_cur;
         a.tp = e->pair_tp;
         launch_inv_pair(e->plan2, a, st);
     }
@@ -728,7 +729,7 @@ static int run_chunk_direct(bfir_engine *e, const void *d_in, long in_stride, vo
         a.n_t = tc; a.n_ch = e->GC;
         a.in_scale = e->out_scale; a.full_output = 0; a.interleaved = e->ilv;
         a.raw_bytes = e->out_bytes; a.raw = d_out; a.raw_eng_stride = out_stride / e->out_bytes; a.frame_off = frame_off; a.C = e->C;
-        a.max = e->of_max; a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.max = e->of_max; a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base; a.bad_host = e->bad_host_cur;
         launch_inv(e->plan, a, st);
     }
     if (e->pipe3 && !il) HIP_TRY(hipEventRecord(e->ev_inv[par], st));
@@ -820,7 +821,7 @@ static int run_chunk(bfir_engine *e, const void *d_in, long in_stride, void *d_o
         a.n_frames = (long)tc * e->L;
         a.src = e->tout; a.src_ch_stride = t_stride;
         a.realsize = e->s; a.L = e->L; a.max = e->of_max;
-        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base;
+        a.overflow = e->d_of; a.of_shard_stride = e->GC; a.bad_block = e->d_bad; a.block_base = block_base; a.bad_host = e->bad_host_cur;
         a.dither_tab = e->d_dither_tab; a.dither_size = e->dither_size; a.dither_state = e->d_dither_state;
         launch_stage_out(a, st);
     }
@@ -991,7 +992,8 @@ static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_bloc
     rc = ensure_staging(e, kSmallRun);
     if (rc != BFIR_OK) return rc;
     if (e->async_pending) { HIP_TRY(hipDeviceSynchronize()); e->async_pending = false; }
-    if (!e->h_bad) { HIP_TRY(hipHostMalloc((void **)&e->h_bad, sizeof(int), hipHostMallocDefault)); }
+    if (!e->h_bad) { HIP_TRY(hipHostMalloc((void **)&e->h_bad, sizeof(int) * kSmallRun, hipHostMallocDefault)); }
+    for (int t = 0; t < kSmallRun; t++) e->h_bad[t] = 0;
     const size_t per_in = (size_t)n_blocks * e->L * e->C * e->in_bytes, per_out = (size_t)n_blocks * e->L * e->C * e->out_bytes;
     memcpy(e->pin_in[0], inbuf, per_in * e->n_eng);       // engine after engine, n_blocks * L frames each: same layout
     // Frames wider than what one workgroup of the fused FFT kernels consumes (a channel pair or one channel of
@@ -1009,9 +1011,12 @@ static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_bloc
         src = e->dev_in[0]; dst = e->dev_out[0];
     }
     e->inline_launch = true;
-    for (int c0 = 0; c0 < n_blocks && rc == BFIR_OK; c0 += e->chunk)       // the work buffers hold e->chunk blocks
+    for (int c0 = 0; c0 < n_blocks && rc == BFIR_OK; c0 += e->chunk) {     // the work buffers hold e->chunk blocks
+        e->bad_host_cur = e->h_bad + c0;                                   // the NaN verdict of block c0 + t lands in h_bad[c0 + t]
         rc = run_chunk(e, src, (long)per_in, dst, (long)per_out, (long)c0 * e->L,
                        std::min(e->chunk, n_blocks - c0), c0, e->stream, nullptr);
+    }
+    e->bad_host_cur = nullptr;
     e->inline_launch = false;
     if (rc != BFIR_OK) return rc;
     if (bounce) {
@@ -1019,11 +1024,14 @@ static int run_small(bfir_engine *e, const void *inbuf, void *outbuf, int n_bloc
         hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, e->stream, (uint4 *)e->pin_out[0],
                            (const uint4 *)e->dev_out[0], n16);
     }
-    HIP_TRY(hipMemcpyAsync(e->h_bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    // no copy of the verdict: the kernels flagged bad blocks in pinned host memory themselves (one 4-byte copy was a blit
+    // kernel of 3.5 us plus its launch, a tenth of the call)
     HIP_TRY(hipStreamSynchronize(e->stream));
     drain_spans(e);
     memcpy(outbuf, e->pin_out[0], per_out * e->n_eng);
-    if (*e->h_bad != 0x7f7f7f7f) {
+    bool bad = false;
+    for (int t = 0; t < n_blocks; t++) bad = bad || e->h_bad[t] != 0;
+    if (bad) {
         HIP_TRY(hipMemset(e->d_bad, 0x7f, sizeof(int)));
         bfir_logf("NaN or Inf values in the system! Invalid input? Aborting.\n");
         return BFIR_ERR_NONFINITE;

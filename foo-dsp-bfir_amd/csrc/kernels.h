@@ -26,6 +26,15 @@ __device__ __forceinline__ DevOverflow *of_shard(DevOverflow *base, long shard_s
     return base + (long)(blockIdx.x & (BFIR_OF_SHARDS - 1)) * shard_stride;
 }
 
+// brutefir.cpp:316-321's verdict: block t of this launch has a non-finite sample 0.  The first such block of a run is kept
+// by atomicMin in HBM; the latency path (a handful of blocks per call, run_small) also gets one flag per block in pinned
+// host memory -- plain, idempotent stores, visible with the stream's end -- so that no copy has to follow the kernels.
+template <typename A> __device__ __forceinline__ void flag_bad(const A &a, int t)
+{
+    atomicMin(a.bad_block, a.block_base + t);
+    if (a.bad_host) a.bad_host[t] = 1;
+}
+
 // Sample formats (brutefir/global.h:24-34; table of brutefir.cpp:435-538, little-endian host).
 struct FmtInfo { int bytes; bool isfloat; bool big_endian; };
 inline FmtInfo fmt_info(int fmt)
@@ -81,6 +90,7 @@ struct StageOutArgs {
     DevOverflow *overflow;         // [n_eng*C]
     long of_shard_stride = 0;
     int *bad_block;                // atomicMin of the first block with a non-finite sample 0
+    int *bad_host = nullptr;       // latency path: one flag per block of the launch in pinned host memory (flag_bad)
     int block_base;                // index of the chunk's first block within the run
     int fmt = 0;                   // BF_SAMPLE_FORMAT_* code; 0 = FLOAT_LE / FLOAT64_LE by raw_bytes
     // HP-TPDF dither (integer formats only, dither.hip): the shared random table and one state per global channel
@@ -176,6 +186,7 @@ struct InvArgs {
     int raw_bytes = 0;
     void *raw = nullptr; long raw_eng_stride = 0, frame_off = 0; int C = 0;
     double max = 1.0; DevOverflow *overflow = nullptr; int *bad_block = nullptr; int block_base = 0;
+    int *bad_host = nullptr;                       // as in StageOutArgs
     long of_shard_stride = 0;
 };
 void launch_inv(const FftPlan &plan, const InvArgs &a, hipStream_t s);
@@ -208,6 +219,7 @@ struct InvPairArgs {
     int C, n_eng, n_t;
     float scale, max;
     DevOverflow *overflow; int *bad_block; int block_base;
+    int *bad_host = nullptr;                             // as in StageOutArgs
     long of_shard_stride = 0;
     int tp = 0;                                          // pairs in time, as in FwdPairArgs
 #ifdef BFIR_EXPERIMENT_ALIAS

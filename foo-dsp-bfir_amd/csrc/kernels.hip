@@ -771,7 +771,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
                 const Bits b0 = (v0 == v0) ? abs_bits(v0) : (Bits)0, b1 = (v1 == v1) ? abs_bits(v1) : (Bits)0;
                 mx = b0 > mx ? b0 : mx; mx = b1 > mx ? b1 : mx;
                 // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-                if (m == 0 && !isfinite((double)v0)) atomicMin(a.bad_block, a.block_base + t);
+                if (m == 0 && !isfinite((double)v0)) flag_bad(a, t);
             }
         }
 #pragma unroll
@@ -822,6 +822,15 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT * CPW) void k_inv(InvArgs a,
 }
 
 // ---------------------------------------------------------------------------
+// k_inv_run has no register to spare for flag_bad's second store (256 VGPRs: the ISA audit found 8 bytes of scratch), so on the
+// latency path one thread turns its atomicMin verdict into the host flag afterwards -- what the 4-byte copy used to cost, for
+// the engines on this kernel only (fp64 with odd channel counts).
+__global__ void k_publish_bad(const int *__restrict__ bad_block, int block_base, int n_t, int *__restrict__ bad_host)
+{
+    const int b = *bad_block - block_base;
+    if (b >= 0 && b < n_t) bad_host[b] = 1;
+}
+
 // k_inv_run: the inverse kernel of fp64 engines in direct mode, one channel per workgroup, as a RUN of blocks
 // ---------------------------------------------------------------------------
 // k_fwd_run's counterpart: the product spectrum of block t + 1 (N doubles: 32 bytes x P / 2 per lane) is fetched into
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(FftCfg<LOG2M>::NT, 2) void k_inv_run(InvArgs a, con
                 const Bits b0 = (v0 == v0) ? abs_bits(v0) : (Bits)0, b1 = (v1 == v1) ? abs_bits(v1) : (Bits)0;
                 mx = b0 > mx ? b0 : mx; mx = b1 > mx ? b1 : mx;
                 // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-                if (m0 == 0 && tid == 0 && !isfinite(v0)) atomicMin(a.bad_block, a.block_base + t);
+                if (m0 == 0 && tid == 0 && !isfinite(v0)) atomicMin(a.bad_block, a.block_base + t);   // (no host flag here: see k_publish_bad)
             }
         });
 #pragma unroll
@@ -984,10 +993,15 @@ template <typename T, int LOG2M> static void launch_inv_t(const FftPlan &plan, c
                     const int runs = (a.n_t + len - 1) / len;
 #define BFIR_LAUNCH_INV_RUN(TR_, IL_) hipLaunchKernelGGL((k_inv_run<LOG2M, TR_, IL_>), dim3(runs * a.n_ch), dim3(FftCfg<LOG2M>::NT), 0, s, a, (const double2 *)plan.twb, (const double2 *)plan.ws, len)
                     if constexpr (LOG2M <= BFIR_PAIRS64_MAX_LOG2M) {
-                        if (a.interleaved) { if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RUN(float, true); else BFIR_LAUNCH_INV_RUN(double, true); return; }
+                        if (a.interleaved) {
+                            if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RUN(float, true); else BFIR_LAUNCH_INV_RUN(double, true);
+                            if (a.bad_host) hipLaunchKernelGGL(k_publish_bad, dim3(1), dim3(1), 0, s, a.bad_block, a.block_base, a.n_t, a.bad_host);
+                            return;
+                        }
                     }
                     if (a.raw_bytes == 4) BFIR_LAUNCH_INV_RUN(float, false); else BFIR_LAUNCH_INV_RUN(double, false);
 #undef BFIR_LAUNCH_INV_RUN
+                    if (a.bad_host) hipLaunchKernelGGL(k_publish_bad, dim3(1), dim3(1), 0, s, a.bad_block, a.block_base, a.n_t, a.bad_host);
                     return;
                 }
             }
@@ -2376,7 +2390,7 @@ template <typename T, typename TR, int WB> __global__ __launch_bounds__(STAGE_TH
                 const Bits bits = (v == v) ? abs_bits(v) : (Bits)0;
                 mx[c] = bits > mx[c] ? bits : mx[c];
                 // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-                if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+                if (first_of_block && !isfinite((double)v)) flag_bad(a, (int)(f / a.L));
             }
         }
         W *p = (W *)(raw + f * a.spacing * (long)sizeof(TR));
@@ -2449,7 +2463,7 @@ template <typename T> __global__ __launch_bounds__(STAGE_THREADS) void k_stage_o
         for (int c = 0; c < BFIR_MAXCH; c++) {
             if (c < C) {
                 T v = src[(long)c * a.src_ch_stride + f];
-                if (first_of_block && !isfinite((double)v)) atomicMin(a.bad_block, a.block_base + (int)(f / a.L));
+                if (first_of_block && !isfinite((double)v)) flag_bad(a, (int)(f / a.L));
                 unsigned long long u;
                 if (isfloat) {
                     cnt[c] += ((v < (T)0) ? (v < rmin) : (v > rmax)) ? 1u : 0u;

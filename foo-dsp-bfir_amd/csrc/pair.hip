@@ -180,7 +180,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT) void k_inv_pair(InvPairArgs a, c
             const unsigned int b1 = (v.y == v.y) ? __float_as_uint(fabsf(v.y)) : 0u;
             mx0 = b0 > mx0 ? b0 : mx0; mx1 = b1 > mx1 ? b1 : mx1;
             // brutefir/brutefir.cpp:316-321: only sample 0 of each block is checked
-            if (n == 0 && !(isfinite(v.x) && isfinite(v.y))) atomicMin(a.bad_block, a.block_base + t);
+            if (n == 0 && !(isfinite(v.x) && isfinite(v.y))) flag_bad(a, t);
         }
     }
 #pragma unroll
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, inv_ps_min_waves<LOG2N>()) void 
     // Without this wait the compiler reuses those registers below -- for the ADDRESSES of the atomics, which the
     // late zeros then turn into a null pointer (seen as a sporadic "memory access fault on address (nil)").
     asm_wait_vmcnt<0>(qa, qb);
-    if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
+    if (bad != 0x7fffffff) flag_bad(a, bad);
     unsigned int mx0 = __float_as_uint(pk0), mx1 = __float_as_uint(pk1);   // non-negative floats order like their bits
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(FftCfg<LOG2N>::NT, inv_ps_min_waves<LOG2N>()) void 
         }
     }
     asm_wait_vmcnt<0>(qa, qb);                                           // see k_inv_pair_ps
-    if (bad != 0x7fffffff) atomicMin(a.bad_block, a.block_base + bad);
+    if (bad != 0x7fffffff) flag_bad(a, bad);
     unsigned int mx0 = __float_as_uint(fmaxf(pk0, pk1)), mx1 = 0u;       // one channel: its peak over both blocks
     c0 += c1; c1 = 0u;
 #pragma unroll

@@ -545,3 +545,48 @@ def test_pinned_frame_buffers_skip_the_staging_copies_with_the_same_bits(orc, bf
     with env_override(BFIR_NO_PINNED_DIRECT="1"):       # the switch puts pinned buffers back on the staging path
         xin = bfir.pinned_frames(bfir.SAMPLE_FORMAT_FLOAT_LE, shape); xin[...] = x.reshape(shape)
         assert np.array_equal(engine().run(xin)[1], want)
+
+
+@pytest.mark.parametrize("s,L,C,in_fmt,out_fmt", [
+    (4, 1024, 2, None, None),       # fp32 channel-pair kernels
+    (4, 1024, 3, None, None),       # fp32 blocks paired in time
+    (4, 4096, 8, None, None),       # ... frames wide enough for the HBM bounce
+    (8, 1024, 2, 8, 8),             # the plug-in as shipped: fp64, float32 stereo frames (k_inv with channel pairs)
+    (8, 1024, 3, 8, 8),             # fp64, odd channel count (k_inv_run: verdict published by its own kernel)
+    (8, 1024, 1, 10, 10),           # fp64 mono, float64 frames
+    (4, 256, 2, 2, 2),              # 16-bit integer frames: staging kernels
+    (4, 64, 2, None, None),         # below the fast paths' sizes
+])
+def test_latency_path_reports_nonfinite_blocks_without_a_copy(orc, bfir, s, L, C, in_fmt, out_fmt):
+    """One to four blocks per call (the plug-in's pattern, foo_dsp_bfir.cpp:311-349): the kernels flag a block whose sample 0 is
+    not finite (brutefir.cpp:316-321) in pinned host memory themselves; every inverse / staging kernel family has to."""
+    B = 3
+    rng = np.random.default_rng(L + C)
+    dt = orc.real_dtype(s)
+    h = orc.synth_ir(rng, C, B * L, dt)
+    x = orc.synth_audio(rng, 8 * L, C, np.float32)
+    if in_fmt == 2:
+        x = np.round(x * 20000).astype("<i2")
+    elif in_fmt == 10:
+        x = x.astype(np.float64)
+
+    def engine():
+        e = bfir.Brutefir(L, B, s, C, in_fmt, out_fmt)
+        assert e.set_coeff(h) == 0
+        return e
+
+    e = engine()
+    for t in range(4):                                   # clean blocks, one per call: no false alarm
+        assert e.run(x[t * L:(t + 1) * L])[0] == 0
+    assert e.run(x[4 * L:8 * L])[0] == 0                 # four blocks in one call
+    if in_fmt == 2:
+        return                                           # integer frames cannot carry a NaN in
+    for nblk, bad_at in ((1, 0), (3, 1), (4, 3)):
+        e = engine()
+        assert e.run(x[:2 * L])[0] == 0
+        xb = x[2 * L:(2 + nblk) * L].copy()
+        xb[bad_at * L + 7, C - 1] = np.nan
+        assert e.run(xb)[0] == -1, (nblk, bad_at)
+    e = engine(); e.set_chunk(1)                         # one block per launch inside a four-block call
+    xb = x[:4 * L].copy(); xb[2 * L + 1, 0] = np.inf
+    assert e.run(xb)[0] == -1

@@ -66,6 +66,16 @@ def test_no_device_means_error_not_fallback(bfir):
     with pytest.raises(bfir.BfirError):
         bfir.FftwConvolver(1024, 4)
     assert b"no HIP device" in lib.bfir_strerror(bfir.ERR_NO_DEVICE)
+    # the newer entry points fail the same way: no page-locked memory, no td convolver, no plan -- never a CPU stand-in
+    assert not lib.bfir_pinned_malloc(4096)
+    with pytest.raises(bfir.BfirError):
+        bfir.pinned_frames(bfir.SAMPLE_FORMAT_FLOAT_LE, (16, 2))
+    err = C.c_int(0)
+    taps = (C.c_float * 4)(1, 2, 3, 4)
+    assert not lib.bfir_td_new(taps, 4, 4, 0, C.byref(err)) and err.value == bfir.ERR_NO_DEVICE
+    assert lib.bfir_td_block_length(5) == 8 and lib.bfir_td_block_length(1) == -1      # pure arithmetic: no device needed
+    with pytest.raises(bfir.BfirError):
+        bfir.FftPlan(3, False, 4)
 
 
 def test_product_does_not_reference_the_oracle():

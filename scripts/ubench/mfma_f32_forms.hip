@@ -65,6 +65,47 @@ template <int FORM, int NACC> __global__ __launch_bounds__(256) void k_rate64(fl
     }
 }
 
+// v_mfma_f64_4x4x4_4B with operands that CHANGE from instruction to instruction (eight A and eight B register pairs in turn, as a
+// Toeplitz pass uses them) and, optionally, each A operand fetched from LDS right before its use: what of the two halves the rate
+// of scripts/ubench/mfma_f64_toeplitz.hip's loop?
+template <int NACC, int LDS> __global__ __launch_bounds__(256) void k_rate64_ops(float *out, int iters)
+{
+    __shared__ double s_a[256 + 64];
+    double a[8], b[8], d[NACC];
+    for (int j = 0; j < 8; j++) { a[j] = threadIdx.x * 1e-3 + j; b[j] = 1.0 + threadIdx.x * 1e-4 - j; }
+    for (int j = threadIdx.x; j < 256 + 64; j += 256) s_a[j] = j * 1e-2;
+    __syncthreads();
+    for (int c = 0; c < NACC; c++) d[c] = 0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double av = a[j];
+            if (LDS) av = s_a[((threadIdx.x & 63) + 4 * j + (it & 63)) & 255];
+#pragma unroll
+            for (int c = 0; c < NACC; c++) d[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b[(j + c) & 7], d[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" : "+v"(a[j]), "+v"(b[j]));
+    }
+    double sum = 0; for (int c = 0; c < NACC; c++) sum += d[c];
+    if (sum == 1.2345) out[0] = (float)sum;
+}
+
+template <int NACC, int LDS> static void rate64_ops(int wps)
+{
+    float *d; CHECK(hipMalloc(&d, 4));
+    const int iters = 4000, blocks = 256 * wps;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_rate64_ops<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, d, 50); CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rate64_ops<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, d, iters); CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double n = (double)iters * 8 * NACC * wps;
+    printf("v_mfma_f64_4x4x4_4B, changing operands%s, %d accumulators, %d wave(s) per SIMD: %.2f ns per MFMA per SIMD, %.1f TFLOP/s\n",
+           LDS ? ", A from LDS" : "", NACC, wps, ms * 1e6 / n, 2.0 * 256 * n * 1024 / (ms * 1e-3) * 1e-12);
+    CHECK(hipFree(d));
+}
+
 template <int FORM, int NACC> static void rate64(const char *name, double macs, int wps)
 {
     float *d; CHECK(hipMalloc(&d, 4));
@@ -144,6 +185,7 @@ int main()
     }
     rate64<0, 1>("v_mfma_f64_16x16x4", 1024, 1);
     rate64<1, 1>("v_mfma_f64_4x4x4_4B", 256, 1);
+    for (int w : {1, 2, 4}) { rate64_ops<4, 0>(w); rate64_ops<4, 1>(w); rate64_ops<2, 1>(w); }
     probe(0, 4);
     probe(1, 16);
     return 0;
